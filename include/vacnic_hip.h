@@ -1,0 +1,272 @@
+/*
+ * vacnic_hip.h — C-ABI of libvacnic_hip.so: the hand-written gfx950 (CDNA4) kernels behind the
+ * VACNIC training step.
+ *
+ * The reference (tingyu215/VACNIC) is pure Python/PyTorch and has no FFI layer; its "plugin
+ * boundary" for this path is the torch.nn operator surface of `src/models` plus three trainer
+ * helpers.  Every entry point below cites the reference op sequence it replaces
+ * (MFULL = src/models/modeling_mmbart_clip_inside_vis_clipcap_ent_type_final_fix_len_enc_self_face_name_ids_crossattn.py,
+ *  TRAIN = train_mmbart_enc_self_face_name_ids_retrieve_crossattn_bart_guide_match.py).
+ * The Python binding a maintainer would add is the ctypes stub shown in INTEGRATION.md and
+ * shipped as vacnic_amd/_lib.py.
+ *
+ * Conventions
+ *  - plain pointers + sizes, no torch types.  All pointers are DEVICE pointers owned by the caller
+ *    (PyTorch-ROCm allocator) and borrowed for the stream lifetime of the call.
+ *  - every call is asynchronous on `stream` (a hipStream_t passed as void*); no hidden syncs,
+ *    no device allocation inside the library.
+ *  - return value: 0 = ok, otherwise a vacnic_status; vacnic_last_error_string() has the text.
+ *  - bf16 tensors are raw uint16 storage ("bf16"), fp32 tensors "f32"; row strides ("ld*") are in
+ *    elements.  bf16 row strides and K must be multiples of 8 (16-byte rows).
+ */
+#ifndef VACNIC_HIP_H
+#define VACNIC_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  VACNIC_OK = 0,
+  VACNIC_BAD_SHAPE = 1,
+  VACNIC_BAD_DTYPE = 2,
+  VACNIC_MISALIGNED = 3,
+  VACNIC_HIP_ERROR = 4,
+  VACNIC_UNSUPPORTED = 5
+} vacnic_status;
+
+const char* vacnic_last_error_string(void);
+int vacnic_version(void);
+
+/* ---- activation / epilogue codes ------------------------------------------------------------ */
+enum { VACNIC_ACT_NONE = 0, VACNIC_ACT_GELU = 1, VACNIC_ACT_TANH = 2, VACNIC_ACT_QUICKGELU = 3 };
+
+/*
+ * GEMM on the MFMA matrix cores (bf16 in, fp32 accumulate).
+ *   out[m][n] = epi( alpha * sum_k X(m,k) * W(n,k) + bias[n] ) (+ residual[m][n])
+ * x_kstrided = 0: X stored [M][K] (X(m,k) = x[m*ldx + k]);  1: stored [K][M] (x[k*ldx + m]).
+ * w_kstrided = 0: W stored [N][K] (torch nn.Linear weight); 1: stored [K][N].
+ *   forward  nn.Linear (MFULL:467-483,738-741 q/k/v/out_proj, fc1/fc2 ...): x_k=0, w_k=0
+ *   dgrad    dX = dY . W          : X=dY, W=weight viewed [K_red=N][N_out=K]   -> w_kstrided=1
+ *   wgrad    dW = dY^T . X        : both operands reduction-strided            -> 1,1 (out_f32_atomic)
+ * epilogue:
+ *   act            VACNIC_ACT_* applied after bias.
+ *   preact         optional bf16 [M][ldo]: receives the pre-activation (saved for backward).
+ *   dact_src       optional bf16 [M][ldo]: if non-null, result is multiplied by act'(dact_src)
+ *                  (fused activation backward in the dgrad of the following Linear).
+ *   residual       optional bf16 [M][ldo] added after the activation.
+ *   out_mode       0: bf16 store, 1: f32 store, 2: f32 atomic accumulate (out += ..; split-K ok)
+ *   split_k        >=1; >1 requires out_mode 2.
+ */
+typedef struct {
+  const void* x; const void* w; const float* bias;
+  void* out; void* preact; const void* dact_src; const void* residual;
+  int64_t M, N, K;
+  int64_t ldx, ldw, ldo;
+  int32_t x_kstrided, w_kstrided;
+  int32_t act, out_mode, split_k;
+  float alpha;
+} vacnic_gemm_args;
+int vacnic_gemm_bf16(const vacnic_gemm_args* a, void* stream);
+
+/*
+ * Fused attention core (replaces bmm -> +mask -> softmax -> bmm of BartAttention.forward,
+ * MFULL:509-548, and nn.MultiheadAttention inside the CLIP ViT).  head_dim must be 64.
+ *   q: [B][Tq][..] bf16, row stride ldq, head h at column offset h*64; likewise k, v (rows Tk).
+ *   out: [B][Tq][H*64] bf16 (row stride ldo) — heads merged, ready for out_proj.
+ *   key_mask: optional uint8 [B][Tk]; 0 => additive finfo(float32).min exactly as _expand_mask
+ *             (MFULL:387-398) does (an all-masked row therefore softmaxes uniformly, like torch).
+ *   causal:   1 => key j masked for query i when j > i (MFULL:373-385).
+ *   scale:    multiplies q.k (reference multiplies q by head_dim**-0.5, MFULL:471).
+ *   lse:      f32 [B][H][Tq] log-sum-exp of the scaled+masked scores (saved for backward).
+ */
+typedef struct {
+  const void* q; const void* k; const void* v; void* out; float* lse;
+  const uint8_t* key_mask;
+  int64_t B, H, Tq, Tk;
+  int64_t ldq, ldk, ldv, ldo;
+  int64_t bsq, bsk, bsv, bso;     /* batch strides in elements */
+  int32_t causal; float scale;
+} vacnic_attn_fwd_args;
+int vacnic_attn_fwd(const vacnic_attn_fwd_args* a, void* stream);
+
+typedef struct {
+  const void* q; const void* k; const void* v; const void* out; const void* dout;
+  const float* lse; float* delta;            /* delta: f32 [B][H][Tq] scratch (rowsum(dO*O)) */
+  void* dq; void* dk; void* dv;              /* bf16, same layouts/strides as q,k,v */
+  const uint8_t* key_mask;
+  int64_t B, H, Tq, Tk;
+  int64_t ldq, ldk, ldv, ldo;
+  int64_t bsq, bsk, bsv, bso;
+  int64_t lddq, lddk, lddv, bsdq, bsdk, bsdv;
+  int32_t causal; float scale;
+} vacnic_attn_bwd_args;
+int vacnic_attn_bwd(const vacnic_attn_bwd_args* a, void* stream);
+
+/*
+ * out = LayerNorm(residual + dropout(x)) * gamma + beta   (post-LN blocks, MFULL:651-653,705-707,
+ * 721-723,742-744; nn.LayerNorm eps=1e-5).  x/residual/out bf16 [R][D]; residual may be NULL
+ * (plain LN: ViT ln_pre/ln_1/ln_2/ln_post, ner_map_layer_norm).  Dropout is Philox keyed on
+ * (seed, row*D+col); p = 0 disables it.  mean/rstd f32 [R] are saved for backward.
+ */
+typedef struct {
+  const void* x; const void* residual; const float* gamma; const float* beta;
+  void* out; float* mean; float* rstd;
+  int64_t R, D; float eps; float p_drop; uint64_t seed;
+} vacnic_add_ln_fwd_args;
+int vacnic_add_ln_fwd(const vacnic_add_ln_fwd_args* a, void* stream);
+
+/* backward: recomputes h = residual + dropout(x) from the saved INPUTS (x, residual) and the saved
+ * mean/rstd; writes dresidual (= d h) and dx (= d h * keep/(1-p)); either may be NULL.  With
+ * p_drop = 0 the two are identical, pass one.  dgamma/dbeta are accumulated with f32 atomics. */
+typedef struct {
+  const void* dout; const void* x; const void* residual; const float* gamma;
+  const float* mean; const float* rstd;
+  void* dresidual; void* dx; float* dgamma; float* dbeta;
+  int64_t R, D; float p_drop; uint64_t seed;
+} vacnic_add_ln_bwd_args;
+int vacnic_add_ln_bwd(const vacnic_add_ln_bwd_args* a, void* stream);
+
+/*
+ * out = dropout(LayerNorm(embed[ids]*scale + pos[t + 2]))  — BartEncoder/BartDecoder prologue,
+ * MFULL:1243-1249,1254-1260,1553-1562; BartLearnedPositionalEmbedding offset 2 (MFULL:401-418).
+ * ids int64 [B][T]; embed f32 or bf16 master table [V][D] (we read the bf16 shadow); pos bf16.
+ */
+typedef struct {
+  const int64_t* ids; const void* embed; const void* pos; const float* gamma; const float* beta;
+  void* out; float* mean; float* rstd;
+  int64_t B, T, D, V; int64_t pos_offset; float embed_scale; float eps; float p_drop; uint64_t seed;
+} vacnic_embed_ln_fwd_args;
+int vacnic_embed_ln_fwd(const vacnic_embed_ln_fwd_args* a, void* stream);
+
+typedef struct {
+  const int64_t* ids; const void* embed; const void* pos; const void* dout; const float* gamma;
+  const float* mean; const float* rstd;
+  float* dembed; float* dpos; float* dgamma; float* dbeta;   /* f32 accumulate (atomics); any may be NULL */
+  int64_t B, T, D, V; int64_t pos_offset; float embed_scale;
+  int64_t padding_idx;                        /* rows with ids == padding_idx get no embedding grad (nn.Embedding) */
+  float p_drop; uint64_t seed;
+} vacnic_embed_ln_bwd_args;
+int vacnic_embed_ln_bwd(const vacnic_embed_ln_bwd_args* a, void* stream);
+
+/*
+ * Cross-entropy over materialised logits (CrossEntropyLoss(ignore_index=pad), TRAIN:287,816).
+ * logits bf16 or f32 [R][ldl] (first V columns valid); targets int64 [R].
+ * vacnic_ce_fwd writes row_lse [R] (and row_loss if non-NULL) and ACCUMULATES *loss_sum / *count
+ * (f32 atomics; caller zeroes them) so that loss = loss_sum / count.
+ * vacnic_ce_bwd writes dlogits bf16 [R][ldd] = (softmax - onehot) * valid * grad_scale * (*grad_out) / (*count);
+ * columns [V, ldd) are zero-filled.  dlogits may alias bf16 logits when ldd == ldl.
+ */
+typedef struct {
+  const void* logits; const int64_t* targets; float* row_lse; float* row_loss; float* loss_sum; float* count;
+  void* dlogits; const float* grad_out; float grad_scale;
+  int64_t R, V, ldl, ldd; int64_t ignore_index; int32_t logits_f32;
+} vacnic_ce_args;
+int vacnic_ce_fwd(const vacnic_ce_args* a, void* stream);
+int vacnic_ce_bwd(const vacnic_ce_args* a, void* stream);
+/* out4 = {total, txt, secla, colam}; total = ce_sum/count + w_secla*secla + w_colam*colam (TRAIN:363).
+ * secla / colam may be NULL (treated as 0). */
+int vacnic_combine_losses(const float* ce_sum, const float* count, const float* secla, const float* colam,
+                          float w_secla, float w_colam, float* out4, void* stream);
+
+/*
+ * CoLaM margin loss (TRAIN:296-307,178-182,820): pool(masked mean over T with the LABEL mask,
+ * nan_to_num(nan=1)) -> L2 normalise -> cos_i = <a_i, b_i> -> mean_i max(0, margin - cos_i).
+ * hs (student, trainable decoder) and hg (guide) bf16 [B][T][D]; mask uint8 [B][T].
+ * fwd writes loss (f32 scalar, overwritten) and saves pooled/normalised rows for bwd.
+ */
+typedef struct {
+  const void* hs; const void* hg; const uint8_t* mask;
+  float* loss; float* cos; float* pooled_s; float* pooled_g;   /* cos [B]; pooled_* f32 [B][D] (raw pooled, pre-norm) */
+  int64_t B, T, D; float margin;
+} vacnic_colam_fwd_args;
+int vacnic_colam_fwd(const vacnic_colam_fwd_args* a, void* stream);
+typedef struct {
+  const float* cos; const float* pooled_s; const float* pooled_g; const uint8_t* mask;
+  void* dhs;                                  /* bf16 [B][T][D], overwritten */
+  int64_t B, T, D; float margin; const float* grad_out; float grad_scale; /* d loss = grad_scale * (*grad_out) */
+} vacnic_colam_bwd_args;
+int vacnic_colam_bwd(const vacnic_colam_bwd_args* a, void* stream);
+
+/*
+ * SECLA face-name loss (BatchSoftmax, TRAIN:631-660): faces f32/bf16 [B][F][D], names f32 [B][N][D].
+ *   M1[i][j][n][f] = <name_{i,n}, face_{j,f}>; L1 = CE_i( sum_n max_f M1 / N , target i )
+ *   M2[i][j][f][n] = <face_{i,f}, name_{j,n}>; L2 = CE_i( sum_f max_n M2 / F , target i )
+ * loss = L1 + L2.  sim f32 [B][N][B][F] scratch holds <name_{i,n}, face_{j,f}> for bwd.
+ */
+typedef struct {
+  const void* faces; const float* names; float* sim; float* logits1; float* logits2; float* loss;
+  int64_t B, F, N, D;
+} vacnic_secla_fwd_args;
+int vacnic_secla_fwd(const vacnic_secla_fwd_args* a, void* stream);
+typedef struct {
+  const void* faces; const float* names; const float* sim; const float* logits1; const float* logits2;
+  void* dfaces;                               /* bf16 [B][F][D], overwritten */
+  float* wsim;                                /* f32 [B][N][B][F] scratch: d loss / d sim */
+  int64_t B, F, N, D; const float* grad_out; float grad_scale;
+} vacnic_secla_bwd_args;
+int vacnic_secla_bwd(const vacnic_secla_bwd_args* a, void* stream);
+
+/* Per-name mean of LN(embed_ner(ids)*scale + pos) — get_embedding_ner, TRAIN:112-133 (unmasked
+ * mean over the Ln tokens, pads included).  ids int64 [B][Nn][Ln] -> out f32 [B][Nn][D]. */
+typedef struct {
+  const int64_t* ids; const void* embed; const void* pos; const float* gamma; const float* beta;
+  float* out; int64_t B, Nn, Ln, D, V; int64_t pos_offset; float embed_scale; float eps;
+} vacnic_name_embed_args;
+int vacnic_name_embed_mean(const vacnic_name_embed_args* a, void* stream);
+
+/*
+ * Fused AdamW over one flat fp32 arena (torch.optim.AdamW semantics, TRAIN:91):
+ *   p *= (1 - lr*wd); m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+ *   p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ * lr, step are read from device memory (graph-capture safe): hyper = {lr, step(as float)}.
+ * Also refreshes the bf16 shadow and zeroes the gradient.  grad_scale multiplies g first
+ * (1/world_size for DDP averaging).
+ */
+typedef struct {
+  float* p; float* g; float* m; float* v; void* p_bf16; const float* hyper;
+  int64_t n; float beta1, beta2, eps, weight_decay, grad_scale; int32_t zero_grad;
+} vacnic_adamw_args;
+int vacnic_adamw(const vacnic_adamw_args* a, void* stream);
+/* get_linear_schedule_with_warmup on device (TRAIN:99-107): hyper[0] <- base_lr*lambda(k), hyper[1] <- k+1
+ * where k = hyper[1] on entry = optimizer steps already taken.  Call once before vacnic_adamw. */
+int vacnic_lr_step(float* hyper, float base_lr, float warmup_steps, float total_steps, void* stream);
+
+/* ---- small data-movement helpers on the path ------------------------------------------------- */
+/* f32 -> bf16 cast (weight shadow refresh, inputs). */
+int vacnic_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
+int vacnic_cast_bf16_f32(const void* src, float* dst, int64_t n, void* stream);
+/* strided 2-D bf16 copy: dst[r*ldd + c] = src[r*lds + c], used for torch.cat along tokens
+ * (MFULL:666,691) without materialising intermediates; accumulate=1 adds instead (cat backward). */
+int vacnic_copy2d_bf16(const void* src, void* dst, int64_t rows, int64_t cols, int64_t lds, int64_t ldd,
+                       int32_t accumulate, void* stream);
+/* 3-D variant: [B][rows][cols] with batch strides. */
+int vacnic_copy3d_bf16(const void* src, void* dst, int64_t B, int64_t rows, int64_t cols,
+                       int64_t lds, int64_t ldd, int64_t bss, int64_t bsd, int32_t accumulate, void* stream);
+/* CLIP patch embedding im2col (conv1 with kernel = stride = patch, no bias; TRAIN:225-227):
+ * img f32 [B][3][HW][HW] -> patches bf16 [B*g*g][Kp] (k = c*p*p + py*p + px, zero-padded to Kp). */
+int vacnic_im2col_patches(const float* img, void* patches, int64_t B, int64_t HW, int64_t patch, int64_t Kp,
+                          void* stream);
+/* x[b][0] = cls + pos[0]; x[b][1+i] = patch_emb[b][i] + pos[1+i]  (TRAIN:228-229), bf16 out. */
+int vacnic_vit_assemble(const void* patch_emb, const void* cls, const void* pos, void* out,
+                        int64_t B, int64_t G2, int64_t W, void* stream);
+/* int64 ids != pad -> uint8 mask, plus shift_tokens_right (TRAIN:196-217) in one launch. */
+int vacnic_prep_ids(const int64_t* ids, uint8_t* mask, int64_t* shifted, int64_t B, int64_t T,
+                    int64_t pad_id, int64_t start_id, void* stream);
+/* face mask = (face_emb[:, :, -1] != 1) as uint8 (TRAIN:269; pad faces are all-ones rows, DSG:48,124). */
+int vacnic_face_mask(const float* faces, uint8_t* mask, int64_t BF, int64_t D, void* stream);
+/* per-row argmax over V logits (greedy decode / eval_epoch TRAIN:424): lowest index wins ties. */
+int vacnic_argmax_rows(const void* logits, int64_t* out, int64_t R, int64_t V, int64_t ldl,
+                       int32_t logits_f32, void* stream);
+/* sum of bias gradient: dbias[n] += sum_m dy[m][n]  (bf16 dy, f32 atomics). */
+int vacnic_bias_grad(const void* dy, float* dbias, int64_t M, int64_t N, int64_t ldy, void* stream);
+/* out = a + b (bf16) — gradient fan-in where a tensor feeds two consumers */
+int vacnic_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);
+
+/* ---- hardware probes (tests only): verify MFMA / ds_read_tr lane maps assumed by the kernels -- */
+int vacnic_probe_layouts(float* out, const float* src128, int64_t n_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,552 @@
+// Fused attention for gfx950, head_dim 64 — replaces BartAttention.forward's core
+// (bmm -> +mask -> softmax(fp32) -> bmm, MFULL:509-548) and nn.MultiheadAttention in the CLIP ViT.
+// The [B*H, Tq, Tk] score matrix never touches HBM.
+//
+// Structure (all three kernels): a workgroup = 4 waves; each wave owns 32 rows of the "outer"
+// dimension (queries for fwd / dQ, keys for dK,dV) and all waves sweep 64-row tiles of the other
+// one, staged HBM -> LDS by `buffer_load ... lds` (double buffered, zero-filled past the edge).
+// MFMA is v_mfma_f32_32x32x16_bf16 with the outer index on the LANE, so softmax state is a
+// per-lane scalar and each product's accumulator tile is directly the B operand of the next
+// product (no LDS round trip for P / dS).  Operands needed transposed come from the same LDS
+// image through ds_read_b64_tr_b16.  One XOR swizzle serves row reads and transposed reads.
+//
+// Mask semantics follow the reference exactly: masked keys get an ADDITIVE finfo(float32).min
+// (_expand_mask MFULL:387-398, _make_causal_mask :373-385), so a fully masked row softmaxes
+// uniformly like torch; only tile padding (key >= Tk) uses -inf.
+#include "common.h"
+
+namespace {
+
+constexpr float FMIN = -3.4028234663852886e38f;
+constexpr int OOB = 0x7ffffff0;
+constexpr int TILE_B = 64 * 64 * 2;   // one [64][64] bf16 tile = 8 KiB
+
+__device__ __forceinline__ int swz(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
+
+// stage a [64 rows][64 cols] bf16 tile: 512 16-B chunks, 2 per thread (256 threads)
+__device__ __forceinline__ void stage64(__amdgpu_buffer_rsrc_t rsrc, char* tile, int row0, int nrows, int ld,
+                                        int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int blk = wave * 2 + i;              // 8 rows per wave-instruction
+    const int row = blk * 8 + (lane >> 3);
+    const int lc = (lane & 7) ^ swz(row);
+    const int gr = row0 + row;
+    const int voff = gr < nrows ? (int)(((unsigned)gr * (unsigned)ld + (unsigned)(lc * 8)) * 2u) : OOB;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(tile + blk * 1024), 16, voff, 0, 0, 0);
+  }
+}
+
+// row fragment: element j = T[rbase + (l&31)][16*ks + 8*(l>>5) + j]
+__device__ __forceinline__ bf16x8 frag_row(const char* tile, int rbase, int ks, int lane) {
+  const int row = rbase + (lane & 31);
+  const int chunk = 2 * ks + (lane >> 5);
+  return *(const bf16x8*)(tile + row * 128 + ((chunk ^ swz(row)) << 4));
+}
+// transposed fragment: element j = T[rbase + 8*(j>>2) + 4*(l>>5) + (j&3)][cbase + (l&31)]
+// (the k-order an accumulator tile has when reused as the other MFMA operand)
+__device__ __forceinline__ bf16x8 frag_tr(const char* tile, int rbase, int cbase, int lane) {
+  const int g = lane >> 4, i = lane & 15, h = lane >> 5;
+  const int col = cbase + 16 * (g & 1) + 4 * (i & 3);
+  bf16x8 r;
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) {
+    const int row = rbase + 8 * hh + 4 * h + (i >> 2);
+    const char* a = tile + row * 128 + (((col >> 3) ^ swz(row)) << 4) + (col & 7) * 2;
+    bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)LDS_PTR(a));
+    r[4 * hh + 0] = t[0]; r[4 * hh + 1] = t[1]; r[4 * hh + 2] = t[2]; r[4 * hh + 3] = t[3];
+  }
+  return r;
+}
+// registers 8s..8s+7 of a 32x32 accumulator -> bf16 fragment of k-step s
+__device__ __forceinline__ bf16x8 pack_acc(const f32x16& x, int s) {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (short)f2bf(x[8 * s + j]);
+  return r;
+}
+__device__ __forceinline__ bf16x8 gload8(__amdgpu_buffer_rsrc_t rsrc, int voff) {
+  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+  return *(bf16x8*)&v;
+}
+// row index inside a 32x32 accumulator held in register r by lane half h
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
+struct AttnP {
+  const bf16_t* q; const bf16_t* k; const bf16_t* v; bf16_t* out; float* lse;
+  const bf16_t* dout; const float* delta; bf16_t* dq; bf16_t* dk; bf16_t* dv;
+  const uint8_t* key_mask;
+  int B, H, Tq, Tk;
+  int ldq, ldk, ldv, ldo, lddq, lddk, lddv;
+  long bsq, bsk, bsv, bso, bsdq, bsdk, bsdv;
+  int causal; float scale;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const bf16_t* base, int rows, int ld) {
+  const unsigned bytes = rows > 0 ? ((unsigned)(rows - 1) * (unsigned)ld + 64u) * 2u : 0u;
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
+}
+
+// per-key additive bias for the whole key range, in LDS: 0 / FMIN (masked) / -inf (padding)
+__device__ __forceinline__ void fill_key_bias(float* kbias, const uint8_t* mask_row, int Tk, int Tk_pad) {
+  for (int j = threadIdx.x; j < Tk_pad; j += 256) {
+    float b = 0.f;
+    if (j >= Tk) b = -INFINITY;
+    else if (mask_row && mask_row[j] == 0) b = FMIN;
+    kbias[j] = b;
+  }
+}
+
+// =================================================================================================
+// forward:  S^T = K Q^T (keys in registers, query on the lane) -> online softmax -> O^T = V^T P^T
+// =================================================================================================
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.z, hd = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int ql = lane & 31, hh = lane >> 5;
+  const int Tk_pad = (p.Tk + 63) & ~63;
+  float* kbias = (float*)(smem + 4 * TILE_B);
+
+  const bf16_t* qb = p.q + (long)b * p.bsq + hd * 64;
+  const bf16_t* kb = p.k + (long)b * p.bsk + hd * 64;
+  const bf16_t* vb = p.v + (long)b * p.bsv + hd * 64;
+  __amdgpu_buffer_rsrc_t qs = make_rsrc(qb, p.Tq, p.ldq);
+  __amdgpu_buffer_rsrc_t ks = make_rsrc(kb, p.Tk, p.ldk);
+  __amdgpu_buffer_rsrc_t vs = make_rsrc(vb, p.Tk, p.ldv);
+
+  int ntile = Tk_pad >> 6;
+  if (p.causal) ntile = min(ntile, (min(p.Tq, (int)blockIdx.x * 128 + 128) + 63) >> 6);
+
+  stage64(ks, smem, 0, p.Tk, p.ldk, wave, lane);
+  stage64(vs, smem + TILE_B, 0, p.Tk, p.ldv, wave, lane);
+  fill_key_bias(kbias, p.key_mask ? p.key_mask + (long)b * p.Tk : nullptr, p.Tk, Tk_pad);
+
+  // Q fragments (B operand: element j = Q[q][16*ks + 8*hh + j]) straight from HBM
+  bf16x8 qf[4];
+  {
+    const int qrow = q0 + ql;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      qf[s] = gload8(qs, qrow < p.Tq ? (int)(((unsigned)qrow * (unsigned)p.ldq + 16u * s + 8u * hh) * 2u) : OOB);
+  }
+
+  f32x16 o[2];
+  o[0] = (f32x16)(0.f); o[1] = (f32x16)(0.f);
+  float m_run = -INFINITY, l_run = 0.f;
+  const int qidx = q0 + ql;
+
+  for (int t = 0; t < ntile; ++t) {
+    const int cur = t & 1;
+    char* kt = smem + cur * (2 * TILE_B);
+    char* vt = kt + TILE_B;
+    if (t + 1 < ntile) {
+      char* nk = smem + (cur ^ 1) * (2 * TILE_B);
+      stage64(ks, nk, (t + 1) * 64, p.Tk, p.ldk, wave, lane);
+      stage64(vs, nk + TILE_B, (t + 1) * 64, p.Tk, p.ldv, wave, lane);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    lds_barrier();
+
+    // ---- S^T[key][q] for the two 32-key blocks of this tile
+    f32x16 s[2];
+#pragma unroll
+    for (int kb2 = 0; kb2 < 2; ++kb2) {
+      s[kb2] = (f32x16)(0.f);
+#pragma unroll
+      for (int ks4 = 0; ks4 < 4; ++ks4)
+        s[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(kt, kb2 * 32, ks4, lane), qf[ks4], s[kb2], 0, 0, 0);
+    }
+    // ---- scale + masks, tile max
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int kb2 = 0; kb2 < 2; ++kb2) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int kbase = t * 64 + kb2 * 32 + 8 * g + 4 * hh;
+        const f32x4 bias = *(const f32x4*)(kbias + kbase);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = s[kb2][4 * g + e] * p.scale + bias[e];
+          if (p.causal && (kbase + e) > qidx) v += FMIN;
+          s[kb2][4 * g + e] = v;
+          tmax = fmaxf(tmax, v);
+        }
+      }
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m_run, tmax);
+    const float alpha = __expf(m_run - m_new);   // m_run = -inf on the first tile -> 0
+    float psum = 0.f;
+#pragma unroll
+    for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __expf(s[kb2][r] - m_new);
+        s[kb2][r] = e;
+        psum += e;
+      }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+    // ---- O^T[hd][q] += V^T P^T
+#pragma unroll
+    for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        const bf16x8 pf = pack_acc(s[kb2], ss);
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+          o[hb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vt, kb2 * 32 + 16 * ss, hb * 32, lane), pf, o[hb], 0, 0, 0);
+      }
+    lds_barrier();
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.f / l_tot;
+  if (qidx < p.Tq) {
+    bf16_t* orow = p.out + (long)b * p.bso + (long)qidx * p.ldo + hd * 64;
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2 pk = {pack2bf(o[hb][4 * g] * inv, o[hb][4 * g + 1] * inv),
+                    pack2bf(o[hb][4 * g + 2] * inv, o[hb][4 * g + 3] * inv)};
+        *(u32x2*)(orow + hb * 32 + 8 * g + 4 * hh) = pk;
+      }
+    if (p.lse && hh == 0) p.lse[((long)b * p.H + hd) * p.Tq + qidx] = m_run + __logf(l_tot);
+  }
+}
+
+// =================================================================================================
+// delta[b][h][q] = sum_d dO[q][d] * O[q][d]
+// =================================================================================================
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
+                                                         float* __restrict__ delta, int B, int H, int Tq, int ldo,
+                                                         long bso) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long)B * Tq) return;
+  const int b = (int)(row / Tq), q = (int)(row % Tq);
+  const bf16_t* orow = o + (long)b * bso + (long)q * ldo;
+  const bf16_t* drow = dout + (long)b * bso + (long)q * ldo;
+  for (int c = lane; c < H * 8; c += 64) {
+    u32x4 a = *(const u32x4*)(orow + c * 8), d = *(const u32x4*)(drow + c * 8);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      s += __uint_as_float(a[i] << 16) * __uint_as_float(d[i] << 16);
+      s += __uint_as_float(a[i] & 0xffff0000u) * __uint_as_float(d[i] & 0xffff0000u);
+    }
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+    if ((c & 7) == 0) delta[((long)b * H + (c >> 3)) * Tq + q] = s;
+  }
+}
+
+// =================================================================================================
+// dK, dV: wave owns 32 keys (on the lane); sweeps 64-query tiles of Q and dO.
+//   S[q][k]  = Q K^T        (A = Q rows from LDS, B = K from registers)
+//   dP[q][k] = dO V^T       (A = dO rows from LDS, B = V from registers)
+//   dV^T[d][k] += dO^T P    (A = dO^T via tr-read, B = P accumulator)
+//   dK^T[d][k] += Q^T dS    (A = Q^T  via tr-read, B = dS accumulator)
+// =================================================================================================
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.z, hd = blockIdx.y;
+  const int k0 = blockIdx.x * 128 + wave * 32;
+  const int kl = lane & 31, hh = lane >> 5;
+  const int kidx = k0 + kl;
+  // LDS: 2 x {Q tile, dO tile} + 2 x {lse[64], delta[64]}
+  float* stats = (float*)(smem + 4 * TILE_B);
+
+  const bf16_t* qb = p.q + (long)b * p.bsq + hd * 64;
+  const bf16_t* kb = p.k + (long)b * p.bsk + hd * 64;
+  const bf16_t* vb = p.v + (long)b * p.bsv + hd * 64;
+  const bf16_t* dob = p.dout + (long)b * p.bso + hd * 64;
+  __amdgpu_buffer_rsrc_t qs = make_rsrc(qb, p.Tq, p.ldq);
+  __amdgpu_buffer_rsrc_t ks = make_rsrc(kb, p.Tk, p.ldk);
+  __amdgpu_buffer_rsrc_t vs = make_rsrc(vb, p.Tk, p.ldv);
+  __amdgpu_buffer_rsrc_t dos = make_rsrc(dob, p.Tq, p.ldo);
+  const float* lse = p.lse + ((long)b * p.H + hd) * p.Tq;
+  const float* delta = p.delta + ((long)b * p.H + hd) * p.Tq;
+
+  const int nq_tiles = (p.Tq + 63) >> 6;
+  int t_begin = 0;
+  if (p.causal) t_begin = min(nq_tiles, (int)(blockIdx.x * 128) >> 6);   // queries before the first key see none of them
+
+  // K / V fragments of this wave's keys (B operand: element j = K[k][16*ks + 8*hh + j])
+  bf16x8 kf[4], vf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    kf[s] = gload8(ks, kidx < p.Tk ? (int)(((unsigned)kidx * (unsigned)p.ldk + 16u * s + 8u * hh) * 2u) : OOB);
+    vf[s] = gload8(vs, kidx < p.Tk ? (int)(((unsigned)kidx * (unsigned)p.ldv + 16u * s + 8u * hh) * 2u) : OOB);
+  }
+  float kbias = 0.f;
+  if (kidx >= p.Tk) kbias = -INFINITY;
+  else if (p.key_mask && p.key_mask[(long)b * p.Tk + kidx] == 0) kbias = FMIN;
+
+  f32x16 dk[2], dv[2];
+  dk[0] = (f32x16)(0.f); dk[1] = (f32x16)(0.f); dv[0] = (f32x16)(0.f); dv[1] = (f32x16)(0.f);
+
+  auto load_stat = [&](int t) -> float {
+    float v = 0.f;
+    if (tid < 128) {
+      const int qi = t * 64 + (tid & 63);
+      if (tid < 64) v = qi < p.Tq ? lse[qi] : INFINITY;
+      else v = qi < p.Tq ? delta[qi] : 0.f;
+    }
+    return v;
+  };
+
+  if (t_begin < nq_tiles) {
+    const float sv = load_stat(t_begin);
+    stage64(qs, smem, t_begin * 64, p.Tq, p.ldq, wave, lane);
+    stage64(dos, smem + TILE_B, t_begin * 64, p.Tq, p.ldo, wave, lane);
+    if (tid < 128) stats[tid] = sv;
+  }
+  for (int t = t_begin; t < nq_tiles; ++t) {
+    const int cur = (t - t_begin) & 1;
+    char* qt = smem + cur * (2 * TILE_B);
+    char* dot = qt + TILE_B;
+    if (t + 1 < nq_tiles) {
+      char* nq = smem + (cur ^ 1) * (2 * TILE_B);
+      const float sv = load_stat(t + 1);
+      stage64(qs, nq, (t + 1) * 64, p.Tq, p.ldq, wave, lane);
+      stage64(dos, nq + TILE_B, (t + 1) * 64, p.Tq, p.ldo, wave, lane);
+      if (tid < 128) stats[(cur ^ 1) * 128 + tid] = sv;
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    lds_barrier();
+    const float* st = stats + cur * 128;
+
+#pragma unroll
+    for (int qb2 = 0; qb2 < 2; ++qb2) {
+      f32x16 s = (f32x16)(0.f), dp = (f32x16)(0.f);
+#pragma unroll
+      for (int ks4 = 0; ks4 < 4; ++ks4) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(qt, qb2 * 32, ks4, lane), kf[ks4], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(dot, qb2 * 32, ks4, lane), vf[ks4], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int ql0 = qb2 * 32 + 8 * g + 4 * hh;
+        const f32x4 l4 = *(const f32x4*)(st + ql0);
+        const f32x4 d4 = *(const f32x4*)(st + 64 + ql0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = s[4 * g + e] * p.scale + kbias;
+          if (p.causal && kidx > (t * 64 + ql0 + e)) v += FMIN;
+          const float pe = __expf(v - l4[e]);
+          s[4 * g + e] = pe;
+          dp[4 * g + e] = pe * (dp[4 * g + e] - d4[e]) * p.scale;
+        }
+      }
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        const bf16x8 pf = pack_acc(s, ss), dsf = pack_acc(dp, ss);
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+          dv[hb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dot, qb2 * 32 + 16 * ss, hb * 32, lane), pf, dv[hb], 0, 0, 0);
+          dk[hb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt, qb2 * 32 + 16 * ss, hb * 32, lane), dsf, dk[hb], 0, 0, 0);
+        }
+      }
+    }
+    lds_barrier();
+  }
+
+  if (kidx < p.Tk) {
+    bf16_t* dkrow = p.dk + (long)b * p.bsdk + (long)kidx * p.lddk + hd * 64;
+    bf16_t* dvrow = p.dv + (long)b * p.bsdv + (long)kidx * p.lddv + hd * 64;
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2 a = {pack2bf(dk[hb][4 * g], dk[hb][4 * g + 1]), pack2bf(dk[hb][4 * g + 2], dk[hb][4 * g + 3])};
+        u32x2 c = {pack2bf(dv[hb][4 * g], dv[hb][4 * g + 1]), pack2bf(dv[hb][4 * g + 2], dv[hb][4 * g + 3])};
+        *(u32x2*)(dkrow + hb * 32 + 8 * g + 4 * hh) = a;
+        *(u32x2*)(dvrow + hb * 32 + 8 * g + 4 * hh) = c;
+      }
+  }
+}
+
+// =================================================================================================
+// dQ: wave owns 32 queries (on the lane); sweeps 64-key tiles of K and V.
+//   S^T[k][q]  = K Q^T ; dP^T[k][q] = V dO^T ; dQ^T[d][q] += K^T dS^T (A = K^T via tr-read)
+// =================================================================================================
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.z, hd = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int ql = lane & 31, hh = lane >> 5;
+  const int qidx = q0 + ql;
+  const int Tk_pad = (p.Tk + 63) & ~63;
+  float* kbias = (float*)(smem + 4 * TILE_B);
+
+  const bf16_t* qb = p.q + (long)b * p.bsq + hd * 64;
+  const bf16_t* kb = p.k + (long)b * p.bsk + hd * 64;
+  const bf16_t* vb = p.v + (long)b * p.bsv + hd * 64;
+  const bf16_t* dob = p.dout + (long)b * p.bso + hd * 64;
+  __amdgpu_buffer_rsrc_t qs = make_rsrc(qb, p.Tq, p.ldq);
+  __amdgpu_buffer_rsrc_t ks = make_rsrc(kb, p.Tk, p.ldk);
+  __amdgpu_buffer_rsrc_t vs = make_rsrc(vb, p.Tk, p.ldv);
+  __amdgpu_buffer_rsrc_t dos = make_rsrc(dob, p.Tq, p.ldo);
+
+  int ntile = Tk_pad >> 6;
+  if (p.causal) ntile = min(ntile, (min(p.Tq, (int)blockIdx.x * 128 + 128) + 63) >> 6);
+
+  stage64(ks, smem, 0, p.Tk, p.ldk, wave, lane);
+  stage64(vs, smem + TILE_B, 0, p.Tk, p.ldv, wave, lane);
+  fill_key_bias(kbias, p.key_mask ? p.key_mask + (long)b * p.Tk : nullptr, p.Tk, Tk_pad);
+
+  bf16x8 qf[4], dof[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    qf[s] = gload8(qs, qidx < p.Tq ? (int)(((unsigned)qidx * (unsigned)p.ldq + 16u * s + 8u * hh) * 2u) : OOB);
+    dof[s] = gload8(dos, qidx < p.Tq ? (int)(((unsigned)qidx * (unsigned)p.ldo + 16u * s + 8u * hh) * 2u) : OOB);
+  }
+  float lse_q = INFINITY, delta_q = 0.f;
+  if (qidx < p.Tq) {
+    lse_q = p.lse[((long)b * p.H + hd) * p.Tq + qidx];
+    delta_q = p.delta[((long)b * p.H + hd) * p.Tq + qidx];
+  }
+  f32x16 dq[2];
+  dq[0] = (f32x16)(0.f); dq[1] = (f32x16)(0.f);
+
+  for (int t = 0; t < ntile; ++t) {
+    const int cur = t & 1;
+    char* kt = smem + cur * (2 * TILE_B);
+    char* vt = kt + TILE_B;
+    if (t + 1 < ntile) {
+      char* nk = smem + (cur ^ 1) * (2 * TILE_B);
+      stage64(ks, nk, (t + 1) * 64, p.Tk, p.ldk, wave, lane);
+      stage64(vs, nk + TILE_B, (t + 1) * 64, p.Tk, p.ldv, wave, lane);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    lds_barrier();
+#pragma unroll
+    for (int kb2 = 0; kb2 < 2; ++kb2) {
+      f32x16 s = (f32x16)(0.f), dp = (f32x16)(0.f);
+#pragma unroll
+      for (int ks4 = 0; ks4 < 4; ++ks4) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(kt, kb2 * 32, ks4, lane), qf[ks4], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(vt, kb2 * 32, ks4, lane), dof[ks4], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int kbase = t * 64 + kb2 * 32 + 8 * g + 4 * hh;
+        const f32x4 bias = *(const f32x4*)(kbias + kbase);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = s[4 * g + e] * p.scale + bias[e];
+          if (p.causal && (kbase + e) > qidx) v += FMIN;
+          const float pe = __expf(v - lse_q);
+          dp[4 * g + e] = pe * (dp[4 * g + e] - delta_q) * p.scale;
+        }
+      }
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        const bf16x8 dsf = pack_acc(dp, ss);
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+          dq[hb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt, kb2 * 32 + 16 * ss, hb * 32, lane), dsf, dq[hb], 0, 0, 0);
+      }
+    }
+    lds_barrier();
+  }
+  if (qidx < p.Tq) {
+    bf16_t* drow = p.dq + (long)b * p.bsdq + (long)qidx * p.lddq + hd * 64;
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2 a = {pack2bf(dq[hb][4 * g], dq[hb][4 * g + 1]), pack2bf(dq[hb][4 * g + 2], dq[hb][4 * g + 3])};
+        *(u32x2*)(drow + hb * 32 + 8 * g + 4 * hh) = a;
+      }
+  }
+}
+
+int check_common(int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                 const char* who) {
+  if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0) {
+    vacnic_set_error("%s: empty problem B=%ld H=%ld Tq=%ld Tk=%ld", who, (long)B, (long)H, (long)Tq, (long)Tk);
+    return VACNIC_BAD_SHAPE;
+  }
+  if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 7)) {
+    vacnic_set_error("%s: row strides must be multiples of 8 elements", who);
+    return VACNIC_MISALIGNED;
+  }
+  if (Tk > 8192 || H > 65535 || B > 65535) {
+    vacnic_set_error("%s: Tk=%ld / H / B beyond supported range", who, (long)Tk);
+    return VACNIC_UNSUPPORTED;
+  }
+  return VACNIC_OK;
+}
+
+}  // namespace
+
+extern "C" int vacnic_attn_fwd(const vacnic_attn_fwd_args* a, void* stream) {
+  VCHECK(a && a->q && a->k && a->v && a->out, VACNIC_BAD_SHAPE, "attn_fwd: null operand");
+  if (int e = check_common(a->B, a->H, a->Tq, a->Tk, a->ldq, a->ldk, a->ldv, a->ldo, "attn_fwd")) return e;
+  VCHECK(aligned16(a->q) && aligned16(a->k) && aligned16(a->v) && aligned16(a->out) && !(a->bsq & 7) && !(a->bsk & 7) &&
+         !(a->bsv & 7) && !(a->bso & 7), VACNIC_MISALIGNED, "attn_fwd: pointers/batch strides must be 16-byte aligned");
+  AttnP p = {};
+  p.q = (const bf16_t*)a->q; p.k = (const bf16_t*)a->k; p.v = (const bf16_t*)a->v; p.out = (bf16_t*)a->out;
+  p.lse = a->lse; p.key_mask = a->key_mask;
+  p.B = (int)a->B; p.H = (int)a->H; p.Tq = (int)a->Tq; p.Tk = (int)a->Tk;
+  p.ldq = (int)a->ldq; p.ldk = (int)a->ldk; p.ldv = (int)a->ldv; p.ldo = (int)a->ldo;
+  p.bsq = a->bsq; p.bsk = a->bsk; p.bsv = a->bsv; p.bso = a->bso;
+  p.causal = a->causal; p.scale = a->scale;
+  const int Tk_pad = (p.Tk + 63) & ~63;
+  dim3 grid((p.Tq + 127) / 128, p.H, p.B);
+  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 4 * TILE_B + Tk_pad * 4, (hipStream_t)stream, p);
+  VLAUNCH_CHECK();
+  return VACNIC_OK;
+}
+
+extern "C" int vacnic_attn_bwd(const vacnic_attn_bwd_args* a, void* stream) {
+  VCHECK(a && a->q && a->k && a->v && a->out && a->dout && a->lse && a->delta && a->dq && a->dk && a->dv,
+         VACNIC_BAD_SHAPE, "attn_bwd: null operand");
+  if (int e = check_common(a->B, a->H, a->Tq, a->Tk, a->ldq, a->ldk, a->ldv, a->ldo, "attn_bwd")) return e;
+  VCHECK(!(a->lddq & 7) && !(a->lddk & 7) && !(a->lddv & 7) && !(a->bsq & 7) && !(a->bsk & 7) && !(a->bsv & 7) &&
+         !(a->bso & 7) && !(a->bsdq & 7) && !(a->bsdk & 7) && !(a->bsdv & 7), VACNIC_MISALIGNED,
+         "attn_bwd: strides must be multiples of 8 elements");
+  AttnP p = {};
+  p.q = (const bf16_t*)a->q; p.k = (const bf16_t*)a->k; p.v = (const bf16_t*)a->v;
+  p.dout = (const bf16_t*)a->dout; p.lse = (float*)a->lse; p.delta = a->delta;
+  p.dq = (bf16_t*)a->dq; p.dk = (bf16_t*)a->dk; p.dv = (bf16_t*)a->dv; p.key_mask = a->key_mask;
+  p.B = (int)a->B; p.H = (int)a->H; p.Tq = (int)a->Tq; p.Tk = (int)a->Tk;
+  p.ldq = (int)a->ldq; p.ldk = (int)a->ldk; p.ldv = (int)a->ldv; p.ldo = (int)a->ldo;
+  p.lddq = (int)a->lddq; p.lddk = (int)a->lddk; p.lddv = (int)a->lddv;
+  p.bsq = a->bsq; p.bsk = a->bsk; p.bsv = a->bsv; p.bso = a->bso;
+  p.bsdq = a->bsdq; p.bsdk = a->bsdk; p.bsdv = a->bsdv;
+  p.causal = a->causal; p.scale = a->scale;
+  hipStream_t s = (hipStream_t)stream;
+  const long rows = (long)p.B * p.Tq;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const bf16_t*)a->out,
+                     (const bf16_t*)a->dout, a->delta, p.B, p.H, p.Tq, p.ldo, (long)p.bso);
+  VLAUNCH_CHECK();
+  const int Tk_pad = (p.Tk + 63) & ~63;
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((p.Tk + 127) / 128, p.H, p.B), dim3(256), 4 * TILE_B + 2 * 128 * 4, s, p);
+  VLAUNCH_CHECK();
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((p.Tq + 127) / 128, p.H, p.B), dim3(256), 4 * TILE_B + Tk_pad * 4, s, p);
+  VLAUNCH_CHECK();
+  return VACNIC_OK;
+}

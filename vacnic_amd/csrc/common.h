@@ -1,0 +1,115 @@
+// Shared device/host helpers for the gfx950 kernels of libvacnic_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/vacnic_hip.h"
+
+typedef unsigned short bf16_t;  // raw bf16 storage
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+// ---- error plumbing (host) -------------------------------------------------------------------
+void vacnic_set_error(const char* fmt, ...);
+#define VCHECK(cond, code, ...)                      \
+  do {                                               \
+    if (!(cond)) {                                   \
+      vacnic_set_error(__VA_ARGS__);                 \
+      return (code);                                 \
+    }                                                \
+  } while (0)
+#define VLAUNCH_CHECK()                                                        \
+  do {                                                                         \
+    hipError_t e__ = hipGetLastError();                                        \
+    if (e__ != hipSuccess) {                                                   \
+      vacnic_set_error("%s:%d launch failed: %s", __FILE__, __LINE__,          \
+                       hipGetErrorString(e__));                                \
+      return VACNIC_HIP_ERROR;                                                 \
+    }                                                                          \
+  } while (0)
+
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// ---- bf16 <-> f32 ------------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+// round-to-nearest-even; NaN stays NaN (quietened)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+
+// ---- wave64 reductions ---------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- activations -----------------------------------------------------------------------------------
+__device__ __forceinline__ float act_fwd(int act, float x) {
+  switch (act) {
+    case VACNIC_ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+    case VACNIC_ACT_TANH: return tanhf(x);
+    case VACNIC_ACT_QUICKGELU: return x / (1.0f + __expf(-1.702f * x));
+    default: return x;
+  }
+}
+// derivative w.r.t. the pre-activation x
+__device__ __forceinline__ float act_bwd(int act, float x) {
+  switch (act) {
+    case VACNIC_ACT_GELU: {
+      float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+      float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+      return cdf + x * pdf;
+    }
+    case VACNIC_ACT_TANH: { float t = tanhf(x); return 1.0f - t * t; }
+    case VACNIC_ACT_QUICKGELU: {
+      float s = 1.0f / (1.0f + __expf(-1.702f * x));
+      return s + 1.702f * x * s * (1.0f - s);
+    }
+    default: return 1.0f;
+  }
+}
+
+// ---- Philox4x32-10 counter RNG (dropout) -------------------------------------------------------------
+// keep-mask for element index idx is derived from philox(key=seed, ctr=idx/4)[idx%4]; fwd and bwd
+// regenerate the same bits, nothing is stored.
+__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                            uint32_t k0, uint32_t k1, uint32_t out[4]) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+    uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += W0; k1 += W1;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// 4 consecutive elements starting at idx4*4; returns 4 uniform uint32
+__device__ __forceinline__ void dropout_bits4(uint64_t seed, uint64_t idx4, uint32_t out[4]) {
+  philox4x32((uint32_t)idx4, (uint32_t)(idx4 >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), out);
+}
+__device__ __forceinline__ uint32_t dropout_threshold(float p) {
+  // keep iff bits >= thr  (P(keep) = 1-p)
+  double t = (double)p * 4294967296.0;
+  return t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
+}

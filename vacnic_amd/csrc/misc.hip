@@ -1,0 +1,236 @@
+// Small data-movement kernels on the VACNIC path (gfx950): token-axis concat copies, CLIP patch
+// im2col, id preprocessing, bias gradients, arg-max.  All HBM/latency-bound, 16-byte accesses
+// where the layout allows.
+#include "common.h"
+
+namespace {
+
+inline unsigned grid_for(long work) {
+  long b = (work + 255) / 256;
+  return (unsigned)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+// dst[b][r][c] (+)= src[b][r][c], cols multiple of 8
+__global__ __launch_bounds__(256) void copy3d_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, long B,
+                                                     long rows, long cols8, long lds, long ldd, long bss, long bsd,
+                                                     int accumulate) {
+  const long total = B * rows * cols8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long c = i % cols8; long r = i / cols8;
+    const long b = r / rows; r = r % rows;
+    const u32x4 s = *(const u32x4*)(src + b * bss + r * lds + c * 8);
+    bf16_t* d = dst + b * bsd + r * ldd + c * 8;
+    if (!accumulate) {
+      *(u32x4*)d = s;
+    } else {
+      u32x4 o = *(u32x4*)d, w;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        w[k] = pack2bf(__uint_as_float(o[k] << 16) + __uint_as_float(s[k] << 16),
+                       __uint_as_float(o[k] & 0xffff0000u) + __uint_as_float(s[k] & 0xffff0000u));
+      *(u32x4*)d = w;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
+                                                  bf16_t* __restrict__ o, long n8) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const u32x4 x = ((const u32x4*)a)[i], y = ((const u32x4*)b)[i];
+    u32x4 w;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      w[k] = pack2bf(__uint_as_float(x[k] << 16) + __uint_as_float(y[k] << 16),
+                     __uint_as_float(x[k] & 0xffff0000u) + __uint_as_float(y[k] & 0xffff0000u));
+    ((u32x4*)o)[i] = w;
+  }
+}
+
+// patches[(b*g + gy)*g + gx][k], k = c*p*p + py*p + px  (conv1 weight [w][3][p][p] flattened)
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, long B, int HW,
+                                                     int p, int Kp) {
+  const int g = HW / p, K = 3 * p * p;
+  const long total = B * g * g * Kp;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % Kp); long r = i / Kp;
+    float v = 0.f;
+    if (k < K) {
+      const int gx = (int)(r % g); r /= g;
+      const int gy = (int)(r % g); const long b = r / g;
+      const int c = k / (p * p), rem = k % (p * p), py = rem / p, px = rem % p;
+      v = img[((b * 3 + c) * HW + gy * p + py) * (long)HW + gx * p + px];
+    }
+    out[i] = f2bf(v);
+  }
+}
+
+// x[b][0] = cls + pos[0]; x[b][1+i] = patch_emb[b*G2+i] + pos[1+i]
+__global__ __launch_bounds__(256) void vit_assemble_kernel(const bf16_t* __restrict__ pe, const bf16_t* __restrict__ cls,
+                                                           const bf16_t* __restrict__ pos, bf16_t* __restrict__ out, long B,
+                                                           int G2, int W) {
+  const long total = B * (G2 + 1) * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int w = (int)(i % W); long r = i / W;
+    const int t = (int)(r % (G2 + 1)); const long b = r / (G2 + 1);
+    const float base = t == 0 ? bf2f(cls[w]) : bf2f(pe[(b * G2 + (t - 1)) * W + w]);
+    out[i] = f2bf(base + bf2f(pos[(long)t * W + w]));
+  }
+}
+
+__global__ void prep_ids_kernel(const int64_t* __restrict__ ids, uint8_t* __restrict__ mask, int64_t* __restrict__ shifted,
+                                long B, long T, int64_t pad, int64_t start) {
+  const long total = B * T;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int64_t v = ids[i];
+    if (mask) mask[i] = v != pad;
+    if (shifted) {
+      int64_t s = (i % T) == 0 ? start : ids[i - 1];
+      if (s == -100) s = pad;
+      shifted[i] = s;
+    }
+  }
+}
+// faces: mask = (face_emb[b][f][D-1] != 1)   (TRAIN:269)
+__global__ void face_mask_kernel(const float* __restrict__ faces, uint8_t* __restrict__ mask, long BF, long D) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < BF) mask[i] = faces[i * D + D - 1] != 1.0f;
+}
+
+template <bool F32>
+__global__ __launch_bounds__(256) void argmax_kernel(const void* __restrict__ logits, int64_t* __restrict__ out, int V, long ldl) {
+  __shared__ float bv[256];
+  __shared__ int bi[256];
+  const long r = blockIdx.x;
+  float best = -INFINITY; int idx = 0x7fffffff;
+  for (int j = threadIdx.x; j < V; j += 256) {
+    const float v = F32 ? ((const float*)logits)[r * ldl + j] : bf2f(((const bf16_t*)logits)[r * ldl + j]);
+    if (idx == 0x7fffffff || v > best) { best = v; idx = j; }   // j ascends: lowest index wins ties
+  }
+  bv[threadIdx.x] = best; bi[threadIdx.x] = idx;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      const float ov = bv[threadIdx.x + s]; const int oi = bi[threadIdx.x + s];
+      if (oi != 0x7fffffff && (bi[threadIdx.x] == 0x7fffffff || ov > bv[threadIdx.x] || (ov == bv[threadIdx.x] && oi < bi[threadIdx.x]))) {
+        bv[threadIdx.x] = ov; bi[threadIdx.x] = oi;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[r] = bi[0];
+}
+
+// dbias[n] += sum_m dy[m][n]; block = 64 column-chunks (512 cols) x 4 row groups
+__global__ __launch_bounds__(256) void bias_grad_kernel(const bf16_t* __restrict__ dy, float* __restrict__ dbias, long M, int N,
+                                                        long ldy, int rows_per_block) {
+  __shared__ float red[4][64 * 8 + 1];
+  const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;           // 8-col chunk
+  const long r0 = (long)blockIdx.y * rows_per_block;
+  const long r1 = min(M, r0 + rows_per_block);
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  if (c * 8 + 8 <= N) {
+    for (long r = r0 + rg; r < r1; r += 4) {
+      const u32x4 d = *(const u32x4*)(dy + r * ldy + c * 8);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { acc[2 * k] += __uint_as_float(d[k] << 16); acc[2 * k + 1] += __uint_as_float(d[k] & 0xffff0000u); }
+    }
+  } else if (c * 8 < N) {
+    for (long r = r0 + rg; r < r1; r += 4)
+      for (int j = 0; j < 8; ++j) if (c * 8 + j < N) acc[j] += bf2f(dy[r * ldy + c * 8 + j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[rg][lane * 8 + j] = acc[j];
+  __syncthreads();
+  for (int e = threadIdx.x; e < 512; e += 256) {
+    const int col = blockIdx.x * 512 + e;
+    if (col < N) atomicAdd(dbias + col, red[0][e] + red[1][e] + red[2][e] + red[3][e]);
+  }
+}
+
+}  // namespace
+
+extern "C" int vacnic_copy3d_bf16(const void* src, void* dst, int64_t B, int64_t rows, int64_t cols, int64_t lds,
+                                  int64_t ldd, int64_t bss, int64_t bsd, int32_t accumulate, void* stream) {
+  VCHECK(src && dst, VACNIC_BAD_SHAPE, "copy3d: null operand");
+  VCHECK((cols & 7) == 0 && (lds & 7) == 0 && (ldd & 7) == 0 && (bss & 7) == 0 && (bsd & 7) == 0 && aligned16(src) && aligned16(dst),
+         VACNIC_MISALIGNED, "copy3d: cols/strides must be multiples of 8 and pointers 16-byte aligned");
+  if (B * rows * cols == 0) return VACNIC_OK;
+  hipLaunchKernelGGL(copy3d_kernel, dim3(grid_for(B * rows * (cols >> 3))), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)src, (bf16_t*)dst, (long)B, (long)rows, (long)(cols >> 3), (long)lds, (long)ldd,
+                     (long)bss, (long)bsd, accumulate);
+  VLAUNCH_CHECK();
+  return VACNIC_OK;
+}
+extern "C" int vacnic_copy2d_bf16(const void* src, void* dst, int64_t rows, int64_t cols, int64_t lds, int64_t ldd,
+                                  int32_t accumulate, void* stream) {
+  return vacnic_copy3d_bf16(src, dst, 1, rows, cols, lds, ldd, 0, 0, accumulate, stream);
+}
+extern "C" int vacnic_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream) {
+  VCHECK(a && b && out, VACNIC_BAD_SHAPE, "add: null operand");
+  VCHECK((n & 7) == 0 && aligned16(a) && aligned16(b) && aligned16(out), VACNIC_MISALIGNED, "add: n must be a multiple of 8, pointers 16-byte aligned");
+  if (n == 0) return VACNIC_OK;
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for(n >> 3)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a,
+                     (const bf16_t*)b, (bf16_t*)out, (long)(n >> 3));
+  VLAUNCH_CHECK();
+  return VACNIC_OK;
+}
+extern "C" int vacnic_im2col_patches(const float* img, void* patches, int64_t B, int64_t HW, int64_t patch, int64_t Kp,
+                                     void* stream) {
+  VCHECK(img && patches, VACNIC_BAD_SHAPE, "im2col: null operand");
+  VCHECK(patch > 0 && HW % patch == 0 && Kp >= 3 * patch * patch, VACNIC_BAD_SHAPE, "im2col: bad geometry");
+  const long g = HW / patch;
+  hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(B * g * g * Kp)), dim3(256), 0, (hipStream_t)stream, img,
+                     (bf16_t*)patches, (long)B, (int)HW, (int)patch, (int)Kp);
+  VLAUNCH_CHECK();
+  return VACNIC_OK;
+}
+extern "C" int vacnic_vit_assemble(const void* patch_emb, const void* cls, const void* pos, void* out, int64_t B,
+                                   int64_t G2, int64_t W, void* stream) {
+  VCHECK(patch_emb && cls && pos && out, VACNIC_BAD_SHAPE, "vit_assemble: null operand");
+  hipLaunchKernelGGL(vit_assemble_kernel, dim3(grid_for(B * (G2 + 1) * W)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)patch_emb, (const bf16_t*)cls, (const bf16_t*)pos, (bf16_t*)out, (long)B, (int)G2, (int)W);
+  VLAUNCH_CHECK();
+  return VACNIC_OK;
+}
+extern "C" int vacnic_prep_ids(const int64_t* ids, uint8_t* mask, int64_t* shifted, int64_t B, int64_t T, int64_t pad_id,
+                               int64_t start_id, void* stream) {
+  VCHECK(ids, VACNIC_BAD_SHAPE, "prep_ids: null ids");
+  if (B * T == 0) return VACNIC_OK;
+  hipLaunchKernelGGL(prep_ids_kernel, dim3(grid_for(B * T)), dim3(256), 0, (hipStream_t)stream, ids, mask, shifted,
+                     (long)B, (long)T, pad_id, start_id);
+  VLAUNCH_CHECK();
+  return VACNIC_OK;
+}
+extern "C" int vacnic_face_mask(const float* faces, uint8_t* mask, int64_t BF, int64_t D, void* stream) {
+  VCHECK(faces && mask, VACNIC_BAD_SHAPE, "face_mask: null operand");
+  if (BF == 0) return VACNIC_OK;
+  hipLaunchKernelGGL(face_mask_kernel, dim3((unsigned)((BF + 255) / 256)), dim3(256), 0, (hipStream_t)stream, faces, mask,
+                     (long)BF, (long)D);
+  VLAUNCH_CHECK();
+  return VACNIC_OK;
+}
+extern "C" int vacnic_argmax_rows(const void* logits, int64_t* out, int64_t R, int64_t V, int64_t ldl, int32_t logits_f32,
+                                  void* stream) {
+  VCHECK(logits && out && V > 0, VACNIC_BAD_SHAPE, "argmax: bad operand");
+  if (R == 0) return VACNIC_OK;
+  if (logits_f32) hipLaunchKernelGGL(argmax_kernel<true>, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, logits, out, (int)V, (long)ldl);
+  else hipLaunchKernelGGL(argmax_kernel<false>, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, logits, out, (int)V, (long)ldl);
+  VLAUNCH_CHECK();
+  return VACNIC_OK;
+}
+extern "C" int vacnic_bias_grad(const void* dy, float* dbias, int64_t M, int64_t N, int64_t ldy, void* stream) {
+  VCHECK(dy && dbias, VACNIC_BAD_SHAPE, "bias_grad: null operand");
+  VCHECK((ldy & 7) == 0 && aligned16(dy), VACNIC_MISALIGNED, "bias_grad: dy rows must be 16-byte aligned");
+  if (M == 0 || N == 0) return VACNIC_OK;
+  const int cb = (int)((N + 511) / 512);
+  int rb = (int)((M + 255) / 256);
+  if (rb > 256) rb = 256;
+  const int rows_per_block = (int)((M + rb - 1) / rb);
+  hipLaunchKernelGGL(bias_grad_kernel, dim3(cb, rb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, dbias, (long)M,
+                     (int)N, (long)ldy, rows_per_block);
+  VLAUNCH_CHECK();
+  return VACNIC_OK;
+}

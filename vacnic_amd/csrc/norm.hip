@@ -1,0 +1,507 @@
+// Row-wise LayerNorm family for gfx950 — HBM-bound kernels: one wave64 per row, 16-byte coalesced
+// loads, wavefront shuffle reductions, fp32 statistics, Philox dropout regenerated (never stored).
+//
+//   add_ln      : LayerNorm(residual + dropout(x))           MFULL:651-653,662-664,678-679,705-707,
+//                                                            721-723,742-744 and decoder 839-886
+//   embed_ln    : dropout(LayerNorm(embed[id]*s + pos[t+2])) MFULL:1243-1249,1254-1260,1553-1562
+//   name_embed  : mean_t LayerNorm(embed_ner[id]*s + pos)    TRAIN:112-133 (get_embedding_ner)
+#include "common.h"
+
+namespace {
+
+constexpr int ROWS_PER_BLOCK = 4;   // 4 waves
+
+__device__ __forceinline__ void load8(const bf16_t* p, float v[8]) {
+  u32x4 r = *(const u32x4*)p;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[2 * i] = __uint_as_float(r[i] << 16);
+    v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float v[8]) {
+  u32x4 r = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+  *(u32x4*)p = r;
+}
+// keep-scale factors for the 8 elements starting at flat index idx (multiple of 8)
+__device__ __forceinline__ void drop8(uint64_t seed, uint64_t idx, uint32_t thr, float inv_keep, float m[8]) {
+  uint32_t b[4];
+  dropout_bits4(seed, idx >> 2, b);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) m[i] = b[i] >= thr ? inv_keep : 0.f;
+  dropout_bits4(seed, (idx >> 2) + 1, b);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) m[4 + i] = b[i] >= thr ? inv_keep : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int NCH>   // chunks of 8 per lane: D <= NCH*512
+__global__ __launch_bounds__(256) void add_ln_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ res,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         bf16_t* __restrict__ out, float* __restrict__ mean_o,
+                                                         float* __restrict__ rstd_o, int64_t R, int D, float eps,
+                                                         float p_drop, uint64_t seed) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const int nchunk = D >> 3;
+  const uint32_t thr = dropout_threshold(p_drop);
+  const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  float h[NCH][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      float xv[8];
+      load8(x + row * D + c * 8, xv);
+      if (p_drop > 0.f) {
+        float m[8];
+        drop8(seed, (uint64_t)row * D + c * 8, thr, inv_keep, m);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xv[j] *= m[j];
+      }
+      if (res) {
+        float rv[8];
+        load8(res + row * D + c * 8, rv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xv[j] += rv[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { h[i][j] = xv[j]; s += xv[j]; }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) h[i][j] = 0.f;
+    }
+  }
+  const float mean = wave_sum(s) / D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { float d = h[i][j] - mean; q += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / D + eps);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      float y[8];
+      f32x4 g0 = *(const f32x4*)(gamma + c * 8), g1 = *(const f32x4*)(gamma + c * 8 + 4);
+      f32x4 b0 = *(const f32x4*)(beta + c * 8), b1 = *(const f32x4*)(beta + c * 8 + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        y[j] = (h[i][j] - mean) * rstd * g0[j] + b0[j];
+        y[4 + j] = (h[i][4 + j] - mean) * rstd * g1[j] + b1[j];
+      }
+      store8(out + row * D + c * 8, y);
+    }
+  }
+  if (lane == 0) {
+    if (mean_o) mean_o[row] = mean;
+    if (rstd_o) rstd_o[row] = rstd;
+  }
+}
+
+// backward: recompute h = residual + dropout(x) from the saved inputs, xhat = (h-mean)*rstd.
+//   dxhat = dout*gamma; dh = rstd*(dxhat - mean(dxhat) - xhat*mean(dxhat*xhat))
+// Each block walks a strided set of rows and keeps per-column dgamma/dbeta partials in registers,
+// then one f32 atomic per column per block.
+template <int NCH>
+__global__ __launch_bounds__(256) void add_ln_bwd_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ x,
+                                                         const bf16_t* __restrict__ res, const float* __restrict__ gamma,
+                                                         const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+                                                         bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                         int64_t R, int D, float p_drop, uint64_t seed) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int nchunk = D >> 3;
+  const uint32_t thr = dropout_threshold(p_drop);
+  const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  float dg[NCH][8], db[NCH][8];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { dg[i][j] = 0.f; db[i][j] = 0.f; }
+
+  for (int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave; row < R; row += (int64_t)gridDim.x * ROWS_PER_BLOCK) {
+    const float mean = mean_i[row], rstd = rstd_i[row];
+    float xh[NCH][8], dxh[NCH][8], msk[NCH][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nchunk) {
+        float xv[8], dv[8];
+        load8(x + row * D + c * 8, xv);
+        if (p_drop > 0.f) {
+          drop8(seed, (uint64_t)row * D + c * 8, thr, inv_keep, msk[i]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) xv[j] *= msk[i][j];
+        }
+        if (res) {
+          float rv[8];
+          load8(res + row * D + c * 8, rv);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) xv[j] += rv[j];
+        }
+        load8(dout + row * D + c * 8, dv);
+        f32x4 g0 = *(const f32x4*)(gamma + c * 8), g1 = *(const f32x4*)(gamma + c * 8 + 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xhat = (xv[j] - mean) * rstd;
+          const float g = j < 4 ? g0[j & 3] : g1[j & 3];
+          const float d = dv[j] * g;
+          xh[i][j] = xhat; dxh[i][j] = d;
+          s1 += d; s2 += d * xhat;
+          dg[i][j] += dv[j] * xhat; db[i][j] += dv[j];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / D; s2 = wave_sum(s2) / D;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nchunk) {
+        float dh[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dh[j] = rstd * (dxh[i][j] - s1 - xh[i][j] * s2);
+        if (dres) store8(dres + row * D + c * 8, dh);
+        if (dx) {
+          if (p_drop > 0.f) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dh[j] *= msk[i][j];
+          }
+          store8(dx + row * D + c * 8, dh);
+        }
+      }
+    }
+  }
+  // cross-wave reduce of dgamma/dbeta through LDS, then one atomic per column per block
+  __shared__ float red[ROWS_PER_BLOCK][64 * 8 + 1];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 8; ++j) red[wave][lane * 8 + j] = pass == 0 ? dg[i][j] : db[i][j];
+      __syncthreads();
+      float* dst = pass == 0 ? dgamma : dbeta;
+      if (dst) {
+        for (int e = threadIdx.x; e < 512; e += 256) {
+          const int c = (e >> 3) + 64 * i;
+          if (c < nchunk) {
+            float t = red[0][e] + red[1][e] + red[2][e] + red[3][e];
+            atomicAdd(dst + c * 8 + (e & 7), t);
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int NCH>
+__global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* __restrict__ ids, const bf16_t* __restrict__ emb,
+                                                           const bf16_t* __restrict__ pos, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, bf16_t* __restrict__ out,
+                                                           float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                           int64_t R, int T, int D, int64_t V, int pos_offset, float scale,
+                                                           float eps, float p_drop, uint64_t seed) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const int nchunk = D >> 3;
+  int64_t id = ids[row];
+  id = id < 0 ? 0 : (id >= V ? V - 1 : id);   // clamp: a bad id must not fault the GPU
+  const int t = (int)(row % T) + pos_offset;
+  const uint32_t thr = dropout_threshold(p_drop);
+  const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  float h[NCH][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      float ev[8], pv[8];
+      load8(emb + id * D + c * 8, ev);
+      load8(pos + (int64_t)t * D + c * 8, pv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { h[i][j] = ev[j] * scale + pv[j]; s += h[i][j]; }
+    }
+  }
+  const float mean = wave_sum(s) / D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { float d = h[i][j] - mean; q += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / D + eps);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      float y[8], m[8];
+      if (p_drop > 0.f) drop8(seed, (uint64_t)row * D + c * 8, thr, inv_keep, m);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        y[j] = (h[i][j] - mean) * rstd * gamma[c * 8 + j] + beta[c * 8 + j];
+        if (p_drop > 0.f) y[j] *= m[j];
+      }
+      store8(out + row * D + c * 8, y);
+    }
+  }
+  if (lane == 0) {
+    if (mean_o) mean_o[row] = mean;
+    if (rstd_o) rstd_o[row] = rstd;
+  }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const int64_t* __restrict__ ids, const bf16_t* __restrict__ emb,
+                                                           const bf16_t* __restrict__ pos, const bf16_t* __restrict__ dout,
+                                                           const float* __restrict__ gamma, const float* __restrict__ mean_i,
+                                                           const float* __restrict__ rstd_i, float* __restrict__ demb,
+                                                           float* __restrict__ dpos, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, int64_t R, int T, int D, int64_t V,
+                                                           int pos_offset, float scale, int64_t padding_idx, float p_drop,
+                                                           uint64_t seed) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int nchunk = D >> 3;
+  const uint32_t thr = dropout_threshold(p_drop);
+  const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  float dg[NCH][8], db[NCH][8];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { dg[i][j] = 0.f; db[i][j] = 0.f; }
+
+  for (int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave; row < R; row += (int64_t)gridDim.x * ROWS_PER_BLOCK) {
+    int64_t id = ids[row];
+    const bool is_pad = (id == padding_idx);
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    const int t = (int)(row % T) + pos_offset;
+    const float mean = mean_i[row], rstd = rstd_i[row];
+    float xh[NCH][8], dxh[NCH][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nchunk) {
+        float ev[8], pv[8], dv[8], m[8];
+        load8(emb + id * D + c * 8, ev);
+        load8(pos + (int64_t)t * D + c * 8, pv);
+        load8(dout + row * D + c * 8, dv);
+        if (p_drop > 0.f) {
+          drop8(seed, (uint64_t)row * D + c * 8, thr, inv_keep, m);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) dv[j] *= m[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xhat = (ev[j] * scale + pv[j] - mean) * rstd;
+          const float d = dv[j] * gamma[c * 8 + j];
+          xh[i][j] = xhat; dxh[i][j] = d;
+          s1 += d; s2 += d * xhat;
+          dg[i][j] += dv[j] * xhat; db[i][j] += dv[j];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / D; s2 = wave_sum(s2) / D;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nchunk) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float dh = rstd * (dxh[i][j] - s1 - xh[i][j] * s2);
+          if (demb && !is_pad) atomicAdd(demb + id * D + c * 8 + j, dh * scale);
+          if (dpos) atomicAdd(dpos + (int64_t)t * D + c * 8 + j, dh);
+        }
+      }
+    }
+  }
+  __shared__ float red[ROWS_PER_BLOCK][64 * 8 + 1];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 8; ++j) red[wave][lane * 8 + j] = pass == 0 ? dg[i][j] : db[i][j];
+      __syncthreads();
+      float* dst = pass == 0 ? dgamma : dbeta;
+      if (dst) {
+        for (int e = threadIdx.x; e < 512; e += 256) {
+          const int c = (e >> 3) + 64 * i;
+          if (c < nchunk) atomicAdd(dst + c * 8 + (e & 7), red[0][e] + red[1][e] + red[2][e] + red[3][e]);
+        }
+      }
+    }
+  }
+}
+
+// mean over Ln tokens of LN(embed*scale + pos): one wave per (b, name)
+template <int NCH>
+__global__ __launch_bounds__(256) void name_embed_kernel(const int64_t* __restrict__ ids, const bf16_t* __restrict__ emb,
+                                                         const bf16_t* __restrict__ pos, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ out,
+                                                         int64_t R, int Ln, int D, int64_t V, int pos_offset, float scale,
+                                                         float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const int nchunk = D >> 3;
+  float acc[NCH][8];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+  for (int t = 0; t < Ln; ++t) {
+    int64_t id = ids[row * Ln + t];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    float h[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nchunk) {
+        float ev[8], pv[8];
+        load8(emb + id * D + c * 8, ev);
+        load8(pos + (int64_t)(t + pos_offset) * D + c * 8, pv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { h[i][j] = ev[j] * scale + pv[j]; s += h[i][j]; }
+      }
+    }
+    const float mean = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nchunk) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { float d = h[i][j] - mean; q += d * d; }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / D + eps);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nchunk) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] += (h[i][j] - mean) * rstd * gamma[c * 8 + j] + beta[c * 8 + j];
+      }
+    }
+  }
+  const float inv = 1.f / Ln;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) out[row * D + c * 8 + j] = acc[i][j] * inv;
+    }
+  }
+}
+
+inline int nch_for(int64_t D) { return (int)((D / 8 + 63) / 64); }
+
+}  // namespace
+
+#define DISPATCH_NCH(nch, KERNEL, grid, stream, ...)                                                    \
+  switch (nch) {                                                                                        \
+    case 1: hipLaunchKernelGGL((KERNEL<1>), grid, dim3(256), 0, stream, __VA_ARGS__); break;            \
+    case 2: hipLaunchKernelGGL((KERNEL<2>), grid, dim3(256), 0, stream, __VA_ARGS__); break;            \
+    case 3: hipLaunchKernelGGL((KERNEL<3>), grid, dim3(256), 0, stream, __VA_ARGS__); break;            \
+    default: hipLaunchKernelGGL((KERNEL<4>), grid, dim3(256), 0, stream, __VA_ARGS__); break;           \
+  }
+
+static int check_d(int64_t D, const char* who) {
+  if (D <= 0 || (D & 7) != 0 || D > 2048) {
+    vacnic_set_error("%s: D=%ld must be a multiple of 8 and <= 2048", who, (long)D);
+    return VACNIC_BAD_SHAPE;
+  }
+  return VACNIC_OK;
+}
+
+extern "C" int vacnic_add_ln_fwd(const vacnic_add_ln_fwd_args* a, void* stream) {
+  VCHECK(a && a->x && a->gamma && a->beta && a->out, VACNIC_BAD_SHAPE, "add_ln_fwd: null operand");
+  if (int e = check_d(a->D, "add_ln_fwd")) return e;
+  if (a->R == 0) return VACNIC_OK;
+  VCHECK(a->p_drop >= 0.f && a->p_drop < 1.f, VACNIC_BAD_SHAPE, "add_ln_fwd: p_drop out of range");
+  VCHECK(aligned16(a->x) && aligned16(a->out) && aligned16(a->gamma) && aligned16(a->beta) &&
+         (!a->residual || aligned16(a->residual)), VACNIC_MISALIGNED, "add_ln_fwd: pointers must be 16-byte aligned");
+  dim3 grid((unsigned)((a->R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
+  DISPATCH_NCH(nch_for(a->D), add_ln_fwd_kernel, grid, (hipStream_t)stream, (const bf16_t*)a->x,
+               (const bf16_t*)a->residual, a->gamma, a->beta, (bf16_t*)a->out, a->mean, a->rstd, a->R, (int)a->D,
+               a->eps, a->p_drop, a->seed);
+  VLAUNCH_CHECK();
+  return VACNIC_OK;
+}
+
+extern "C" int vacnic_add_ln_bwd(const vacnic_add_ln_bwd_args* a, void* stream) {
+  VCHECK(a && a->dout && a->x && a->gamma && a->mean && a->rstd, VACNIC_BAD_SHAPE, "add_ln_bwd: null operand");
+  if (int e = check_d(a->D, "add_ln_bwd")) return e;
+  if (a->R == 0) return VACNIC_OK;
+  int64_t nb = (a->R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+  if (nb > 1024) nb = 1024;
+  dim3 grid((unsigned)nb);
+  DISPATCH_NCH(nch_for(a->D), add_ln_bwd_kernel, grid, (hipStream_t)stream, (const bf16_t*)a->dout,
+               (const bf16_t*)a->x, (const bf16_t*)a->residual, a->gamma, a->mean, a->rstd, (bf16_t*)a->dresidual,
+               (bf16_t*)a->dx, a->dgamma, a->dbeta, a->R, (int)a->D, a->p_drop, a->seed);
+  VLAUNCH_CHECK();
+  return VACNIC_OK;
+}
+
+extern "C" int vacnic_embed_ln_fwd(const vacnic_embed_ln_fwd_args* a, void* stream) {
+  VCHECK(a && a->ids && a->embed && a->pos && a->gamma && a->beta && a->out, VACNIC_BAD_SHAPE, "embed_ln_fwd: null operand");
+  if (int e = check_d(a->D, "embed_ln_fwd")) return e;
+  const int64_t R = a->B * a->T;
+  if (R == 0) return VACNIC_OK;
+  dim3 grid((unsigned)((R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
+  DISPATCH_NCH(nch_for(a->D), embed_ln_fwd_kernel, grid, (hipStream_t)stream, a->ids, (const bf16_t*)a->embed,
+               (const bf16_t*)a->pos, a->gamma, a->beta, (bf16_t*)a->out, a->mean, a->rstd, R, (int)a->T, (int)a->D,
+               a->V, (int)a->pos_offset, a->embed_scale, a->eps, a->p_drop, a->seed);
+  VLAUNCH_CHECK();
+  return VACNIC_OK;
+}
+
+extern "C" int vacnic_embed_ln_bwd(const vacnic_embed_ln_bwd_args* a, void* stream) {
+  VCHECK(a && a->ids && a->embed && a->pos && a->dout && a->gamma && a->mean && a->rstd, VACNIC_BAD_SHAPE,
+         "embed_ln_bwd: null operand");
+  if (int e = check_d(a->D, "embed_ln_bwd")) return e;
+  const int64_t R = a->B * a->T;
+  if (R == 0) return VACNIC_OK;
+  int64_t nb = (R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+  if (nb > 1024) nb = 1024;
+  dim3 grid((unsigned)nb);
+  DISPATCH_NCH(nch_for(a->D), embed_ln_bwd_kernel, grid, (hipStream_t)stream, a->ids, (const bf16_t*)a->embed,
+               (const bf16_t*)a->pos, (const bf16_t*)a->dout, a->gamma, a->mean, a->rstd, a->dembed, a->dpos,
+               a->dgamma, a->dbeta, R, (int)a->T, (int)a->D, a->V, (int)a->pos_offset, a->embed_scale,
+               a->padding_idx, a->p_drop, a->seed);
+  VLAUNCH_CHECK();
+  return VACNIC_OK;
+}
+
+extern "C" int vacnic_name_embed_mean(const vacnic_name_embed_args* a, void* stream) {
+  VCHECK(a && a->ids && a->embed && a->pos && a->gamma && a->beta && a->out, VACNIC_BAD_SHAPE, "name_embed: null operand");
+  if (int e = check_d(a->D, "name_embed")) return e;
+  const int64_t R = a->B * a->Nn;
+  if (R == 0) return VACNIC_OK;
+  dim3 grid((unsigned)((R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
+  DISPATCH_NCH(nch_for(a->D), name_embed_kernel, grid, (hipStream_t)stream, a->ids, (const bf16_t*)a->embed,
+               (const bf16_t*)a->pos, a->gamma, a->beta, a->out, R, (int)a->Ln, (int)a->D, a->V, (int)a->pos_offset,
+               a->embed_scale, a->eps);
+  VLAUNCH_CHECK();
+  return VACNIC_OK;
+}

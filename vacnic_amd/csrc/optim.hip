@@ -1,0 +1,100 @@
+// Fused AdamW over one flat fp32 arena + LR schedule on device (gfx950, HBM-bound: 16 B/param read,
+// 14 B/param written).  Replaces torch.optim.AdamW's per-tensor loop (TRAIN:91,372-374) and
+// get_linear_schedule_with_warmup (TRAIN:99-107).  lr/step live in device memory so the whole
+// step is hipGraph-capturable.
+#include "common.h"
+
+namespace {
+
+// hyper[0] = lr for this step, hyper[1] = step count t (float, 1-based after the increment)
+__global__ void lr_step_kernel(float* hyper, float base_lr, float warmup, float total) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const float k = hyper[1];                 // optimizer steps taken so far == LambdaLR's current_step
+    float lam;
+    if (k < warmup) lam = k / fmaxf(1.f, warmup);
+    else lam = fmaxf(0.f, (total - k) / fmaxf(1.f, total - warmup));
+    hyper[0] = base_lr * lam;
+    hyper[1] = k + 1.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, bf16_t* __restrict__ pb,
+                                                    const float* __restrict__ hyper, long n4, float b1, float b2,
+                                                    float eps, float wd, float gscale, int zero_grad) {
+  const float lr = hyper[0], t = hyper[1];
+  const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
+  const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2), decay = 1.f - lr * wd;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 pv = ((f32x4*)p)[i], gv = ((f32x4*)g)[i], mv = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gr = gv[e] * gscale;
+      float pe = pv[e] * decay;
+      const float me = b1 * mv[e] + (1.f - b1) * gr;
+      const float ve = b2 * vv[e] + (1.f - b2) * gr * gr;
+      pe -= step_size * me / (sqrtf(ve) * inv_sqrt_bc2 + eps);
+      pv[e] = pe; mv[e] = me; vv[e] = ve;
+    }
+    ((f32x4*)p)[i] = pv; ((f32x4*)m)[i] = mv; ((f32x4*)v)[i] = vv;
+    if (zero_grad) ((f32x4*)g)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (pb) ((u32x2*)pb)[i] = (u32x2){pack2bf(pv[0], pv[1]), pack2bf(pv[2], pv[3])};
+  }
+}
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ s, bf16_t* __restrict__ d, long n) {
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 v = ((const f32x4*)s)[i];
+    ((u32x2*)d)[i] = (u32x2){pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+  }
+  if (blockIdx.x == 0)
+    for (long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) d[i] = f2bf(s[i]);
+}
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16_t* __restrict__ s, float* __restrict__ d, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) d[i] = bf2f(s[i]);
+}
+
+inline unsigned grid_for(long work) {
+  long b = (work + 255) / 256;
+  return (unsigned)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+}  // namespace
+
+extern "C" int vacnic_lr_step(float* hyper, float base_lr, float warmup_steps, float total_steps, void* stream) {
+  VCHECK(hyper, VACNIC_BAD_SHAPE, "lr_step: null hyper");
+  hipLaunchKernelGGL(lr_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, hyper, base_lr, warmup_steps, total_steps);
+  VLAUNCH_CHECK();
+  return VACNIC_OK;
+}
+
+extern "C" int vacnic_adamw(const vacnic_adamw_args* a, void* stream) {
+  VCHECK(a && a->p && a->g && a->m && a->v && a->hyper, VACNIC_BAD_SHAPE, "adamw: null operand");
+  VCHECK((a->n & 3) == 0, VACNIC_BAD_SHAPE, "adamw: n=%ld must be a multiple of 4 (pad the arena)", (long)a->n);
+  VCHECK(aligned16(a->p) && aligned16(a->g) && aligned16(a->m) && aligned16(a->v) && (!a->p_bf16 || (((uintptr_t)a->p_bf16) & 7) == 0),
+         VACNIC_MISALIGNED, "adamw: arenas must be 16-byte aligned");
+  if (a->n == 0) return VACNIC_OK;
+  const long n4 = a->n >> 2;
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n4)), dim3(256), 0, (hipStream_t)stream, a->p, a->g, a->m, a->v,
+                     (bf16_t*)a->p_bf16, a->hyper, n4, a->beta1, a->beta2, a->eps, a->weight_decay, a->grad_scale,
+                     a->zero_grad);
+  VLAUNCH_CHECK();
+  return VACNIC_OK;
+}
+
+extern "C" int vacnic_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream) {
+  VCHECK(src && dst, VACNIC_BAD_SHAPE, "cast: null operand");
+  VCHECK(aligned16(src) && (((uintptr_t)dst) & 7) == 0, VACNIC_MISALIGNED, "cast_f32_bf16: misaligned");
+  if (n == 0) return VACNIC_OK;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, (long)n);
+  VLAUNCH_CHECK();
+  return VACNIC_OK;
+}
+extern "C" int vacnic_cast_bf16_f32(const void* src, float* dst, int64_t n, void* stream) {
+  VCHECK(src && dst, VACNIC_BAD_SHAPE, "cast: null operand");
+  if (n == 0) return VACNIC_OK;
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, dst, (long)n);
+  VLAUNCH_CHECK();
+  return VACNIC_OK;
+}
