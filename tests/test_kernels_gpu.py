@@ -1,0 +1,355 @@
+"""Per-kernel parity on the MI355X: each hand-written HIP kernel (called through the C-ABI) against a
+plain PyTorch fp32 reference of the same op on the same seeded inputs.  Tolerances are bf16-level and
+written next to each check."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+FMIN = torch.finfo(torch.float32).min
+
+
+@pytest.fixture(scope="module")
+def K():
+    from vacnic_amd import kernels
+    return kernels
+
+
+def rnd(*shape, scale=1.0, dtype=torch.bfloat16, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to("cuda").to(dtype)
+
+
+def close(a, b, rtol, atol, what=""):
+    a = a.float(); b = b.float()
+    err = (a - b).abs()
+    bound = atol + rtol * b.abs()
+    bad = (err > bound).sum().item()
+    assert bad == 0, f"{what}: {bad}/{a.numel()} off; max err {err.max().item():.4g} (ref max {b.abs().max().item():.4g})"
+
+
+# ---------------------------------------------------------------------------------------------- probes
+def test_probe_layouts(K):
+    out = K.probe_layouts().cpu().numpy()
+    fa = lambda i, k: float((i * 3 + k) % 7 - 3)
+    fb = lambda k, j: float((k * 5 + j * 2) % 9 - 4)
+    A16 = np.array([[fa(i, k) for k in range(32)] for i in range(16)]); B16 = np.array([[fb(k, j) for j in range(16)] for k in range(32)])
+    np.testing.assert_array_equal(out[:256].reshape(16, 16), A16 @ B16, err_msg="16x16x32 lane map")
+    A32 = np.array([[fa(i, k) for k in range(16)] for i in range(32)]); B32 = np.array([[fb(k, j) for j in range(32)] for k in range(16)])
+    C32 = A32 @ B32
+    np.testing.assert_array_equal(out[256:1280].reshape(32, 32), C32, err_msg="32x32x16 lane map")
+    tr = out[1280:1536].reshape(64, 4)
+    for l in range(64):
+        g, i = l >> 4, l & 15
+        for e in range(4):
+            assert tr[l, e] == (g * 4 + e) * 16 + i, f"tr-read lane {l} elem {e}: got {tr[l, e]}"
+    oob = out[1536:1600]
+    np.testing.assert_array_equal(oob[:32], np.arange(32) * 4 + 1.0)
+    np.testing.assert_array_equal(oob[32:], np.zeros(32), err_msg="out-of-range LDS-DMA lanes must write 0")
+    A2 = np.array([[float((i + 2 * k) % 5 - 2) for k in range(32)] for i in range(32)])
+    np.testing.assert_array_equal(out[1600:2624].reshape(32, 32), A2 @ C32, err_msg="accumulator-as-B-operand k order")
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K_", [(256, 256, 128), (300, 200, 72), (2048, 1024, 1024), (64, 20, 80), (4, 2048, 512), (130, 50267, 64)])
+def test_gemm_forward(K, M, N, K_):
+    x = rnd(M, K_, seed=1); w = rnd(N, K_, scale=0.05, seed=2); b = rnd(N, dtype=torch.float32, seed=3)
+    out = K.gemm(x, w, M, N, K_, bias=b)
+    ref = x.float() @ w.float().t() + b
+    close(out, ref, 1e-2, 2e-2 * math.sqrt(K_ / 64) * 0.3, f"gemm NT {M}x{N}x{K_}")
+
+
+def test_gemm_padded_ldo_and_f32_out(K):
+    M, N, K_ = 100, 50267, 64
+    x = rnd(M, K_, seed=1); w = rnd(N, K_, scale=0.05, seed=2)
+    ld = 50272
+    out = torch.full((M, ld), 7.0, device="cuda", dtype=torch.bfloat16)
+    K.gemm(x, w, M, N, K_, out=out, ldo=ld)
+    ref = x.float() @ w.float().t()
+    close(out[:, :N], ref, 1e-2, 1e-2, "padded ldo")
+    assert (out[:, N:] == 7.0).all(), "columns >= N must not be written"
+    o32 = K.gemm(x, w, M, N, K_, out_mode=1)
+    close(o32, ref, 1e-4, 1e-4, "f32 out")
+
+
+@pytest.mark.parametrize("act", ["gelu", "tanh", "quick_gelu"])
+def test_gemm_epilogues(K, act):
+    M, N, K_ = 200, 264, 128
+    x = rnd(M, K_, seed=1); w = rnd(N, K_, scale=0.1, seed=2); b = rnd(N, dtype=torch.float32, seed=3)
+    res = rnd(M, N, seed=4)
+    pre = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    out = K.gemm(x, w, M, N, K_, bias=b, act=act, preact=pre, residual=res)
+    u = x.float() @ w.float().t() + b
+    f = {"gelu": torch.nn.functional.gelu, "tanh": torch.tanh, "quick_gelu": lambda t: t * torch.sigmoid(1.702 * t)}[act]
+    close(pre, u, 1e-2, 1e-2, "preact")
+    close(out, f(u) + res.float(), 1e-2, 2e-2, f"act {act} + residual")
+    # fused activation backward: out = (dy @ w2) * act'(u)
+    dy = rnd(M, 96, seed=5); w2 = rnd(96, N, scale=0.1, seed=6)       # Linear(N -> 96): weight [96, N]
+    du = K.gemm(dy, w2, M, N, 96, w_kstrided=True, act=act, dact_src=pre)
+    uu = pre.float().requires_grad_(True)
+    f(uu).backward(dy.float() @ w2.float())
+    close(du, uu.grad, 2e-2, 2e-2, f"dact {act}")
+
+
+@pytest.mark.parametrize("M,N,K_", [(256, 128, 256), (333, 264, 200), (2048, 1024, 4096)])
+def test_gemm_dgrad_wkstrided(K, M, N, K_):
+    # dX[M,N] = dY[M,K_] @ W[K_,N]   (W is an nn.Linear weight [out=K_, in=N])
+    dy = rnd(M, K_, seed=1); w = rnd(K_, N, scale=0.05, seed=2)
+    out = K.gemm(dy, w, M, N, K_, w_kstrided=True)
+    close(out, dy.float() @ w.float(), 1e-2, 3e-2 * math.sqrt(K_ / 256), "dgrad")
+
+
+@pytest.mark.parametrize("M,N,K_,split", [(128, 128, 256, 1), (264, 200, 1000, 1), (1024, 1024, 4096, 4), (50267, 64, 512, 2)])
+def test_gemm_wgrad_both_kstrided(K, M, N, K_, split):
+    # dW[M=out_features, N=in_features] += dY[K_, M]^T @ X[K_, N]
+    ldy = (M + 7) // 8 * 8
+    dyf = rnd(K_, ldy, seed=1); dyf[:, M:] = 0
+    x = rnd(K_, N, seed=2)
+    acc = torch.ones(M, N, device="cuda", dtype=torch.float32)
+    K.gemm(dyf, x, M, N, K_, out=acc, ldx=ldy, x_kstrided=True, w_kstrided=True, out_mode=2, split_k=split, alpha=0.5)
+    ref = 1.0 + 0.5 * (dyf[:, :M].float().t() @ x.float())
+    close(acc, ref, 2e-3, 2e-2 * math.sqrt(K_ / 256), "wgrad accumulate")
+
+
+# ------------------------------------------------------------------------------------------- attention
+def attn_ref(q, k, v, key_mask, causal, scale):
+    B, Tq, H, hd = q.shape
+    Tk = k.shape[1]
+    s = torch.einsum("bqhd,bkhd->bhqk", q.float() * scale, k.float())
+    if key_mask is not None:
+        s = s + ((1.0 - key_mask.float()) * FMIN)[:, None, None, :]
+    if causal:
+        cm = torch.full((Tq, Tk), FMIN, device=q.device).triu(1)
+        s = s + cm
+    p = torch.softmax(s, dim=-1)
+    return torch.einsum("bhqk,bkhd->bqhd", p, v.float()).reshape(B, Tq, H * hd)
+
+
+SHAPES = [  # B, H, Tq, Tk, masked, causal
+    (2, 4, 128, 128, False, False), (2, 3, 200, 200, True, False), (2, 4, 96, 40, False, False),
+    (3, 2, 80, 84, True, False), (2, 4, 64, 64, False, True), (2, 2, 64, 300, True, False),
+    (1, 2, 257, 257, False, False), (2, 2, 20, 512, True, False), (1, 16, 512, 512, True, False)]
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk,masked,causal", SHAPES)
+def test_attention_fwd_bwd(K, B, H, Tq, Tk, masked, causal):
+    d = H * 64
+    # q from a fused [B,Tq,3d] buffer (stride 3d), k/v from a [B,Tk,2d] buffer: exercises strided views
+    qkv = rnd(B, Tq, 3 * d, seed=1); kv = rnd(B, Tk, 2 * d, seed=2)
+    q = qkv[..., 2 * d:]; k = kv[..., :d]; v = kv[..., d:]
+    mask = None
+    if masked:
+        lens = torch.randint(max(1, Tk // 4), Tk + 1, (B,), generator=torch.Generator().manual_seed(3))
+        mask = (torch.arange(Tk)[None, :] < lens[:, None]).to(torch.uint8).cuda()
+    out, lse = K.attn_fwd(q, k, v, B, H, Tq, Tk, key_mask=mask, causal=causal, scale=0.125)
+    qf = q.float().reshape(B, Tq, H, 64).requires_grad_(True)
+    kf = k.float().reshape(B, Tk, H, 64).requires_grad_(True)
+    vf = v.float().reshape(B, Tk, H, 64).requires_grad_(True)
+    ref = attn_ref(qf, kf, vf, mask, causal, 0.125)
+    close(out, ref, 2e-2, 2e-2, "attn fwd")
+    dout = rnd(B, Tq, d, seed=4)
+    ref.backward(dout.float())
+    dqkv = torch.zeros_like(qkv); dkv = torch.zeros_like(kv)
+    K.attn_bwd(q, k, v, out, dout, lse, dqkv[..., 2 * d:], dkv[..., :d], dkv[..., d:], B, H, Tq, Tk, key_mask=mask,
+               causal=causal, scale=0.125)
+    s = max(1.0, math.sqrt(Tk / 64))
+    close(dqkv[..., 2 * d:], qf.grad.reshape(B, Tq, d), 3e-2, 3e-2 * s, "dq")
+    close(dkv[..., :d], kf.grad.reshape(B, Tk, d), 3e-2, 3e-2 * s, "dk")
+    close(dkv[..., d:], vf.grad.reshape(B, Tk, d), 3e-2, 3e-2 * s, "dv")
+    assert (dqkv[..., :2 * d] == 0).all()
+
+
+def test_attention_fully_masked_row_is_uniform(K):
+    B, H, Tq, Tk = 1, 1, 32, 64
+    q = rnd(B, Tq, 64, seed=1); k = rnd(B, Tk, 64, seed=2); v = rnd(B, Tk, 64, seed=3)
+    mask = torch.zeros(B, Tk, dtype=torch.uint8, device="cuda")
+    out, _ = K.attn_fwd(q, k, v, B, H, Tq, Tk, key_mask=mask)
+    close(out, v.float().mean(1, keepdim=True).expand(B, Tq, 64), 1e-2, 1e-2, "all-masked row = uniform softmax like torch")
+
+
+# ------------------------------------------------------------------------------------------------- LN
+@pytest.mark.parametrize("R,D", [(64, 1024), (37, 768), (5, 512), (128, 2048)])
+def test_add_ln(K, R, D):
+    x = rnd(R, D, seed=1); res = rnd(R, D, seed=2)
+    g = rnd(D, dtype=torch.float32, seed=3) * 0.1 + 1.0; b = rnd(D, dtype=torch.float32, seed=4) * 0.1
+    out, mean, rstd = K.add_ln_fwd(x, res, g, b)
+    xf = x.float().requires_grad_(True); rf = res.float().requires_grad_(True)
+    gf = g.clone().requires_grad_(True); bf = b.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xf + rf, (D,), gf, bf, 1e-5)
+    close(out, ref, 1e-2, 1e-2, "add_ln fwd")
+    dout = rnd(R, D, seed=5)
+    ref.backward(dout.float())
+    dg = torch.zeros(D, device="cuda"); db = torch.zeros(D, device="cuda")
+    dx, dres = K.add_ln_bwd(dout, x, res, g, mean, rstd, dg, db)
+    close(dx, xf.grad, 2e-2, 2e-2, "add_ln dx")
+    assert dres is dx
+    close(dg, gf.grad, 1e-2, 1e-2 * math.sqrt(R), "dgamma"); close(db, bf.grad, 1e-2, 1e-2 * math.sqrt(R), "dbeta")
+    # plain LN (no residual)
+    out2, _, _ = K.add_ln_fwd(x, None, g, b)
+    close(out2, torch.nn.functional.layer_norm(x.float(), (D,), g, b, 1e-5), 1e-2, 1e-2, "plain LN")
+
+
+def test_add_ln_dropout_consistency(K):
+    R, D, p = 256, 1024, 0.1
+    x = rnd(R, D, seed=1); res = torch.zeros(R, D, device="cuda", dtype=torch.bfloat16)
+    g = torch.ones(D, device="cuda"); b = torch.zeros(D, device="cuda")
+    # recover the keep mask from the backward: dx = dh * keep/(1-p), dres = dh
+    out, mean, rstd = K.add_ln_fwd(x, res, g, b, p_drop=p, seed=1234)
+    dout = rnd(R, D, seed=5)
+    dg = torch.zeros(D, device="cuda"); db = torch.zeros(D, device="cuda")
+    dx, dres = K.add_ln_bwd(dout, x, res, g, mean, rstd, dg, db, p_drop=p, seed=1234)
+    keep = (dx.float().abs() > 0) | (dres.float().abs() == 0)
+    frac = keep.float().mean().item()
+    assert abs(frac - (1 - p)) < 0.01, f"keep fraction {frac}"
+    xd = torch.where(keep, x.float() / (1 - p), torch.zeros_like(x.float()))
+    close(out, torch.nn.functional.layer_norm(xd, (D,), g, b, 1e-5), 2e-2, 2e-2, "LN(dropout(x)) with the recovered mask")
+    out2, _, _ = K.add_ln_fwd(x, res, g, b, p_drop=p, seed=1234)
+    assert torch.equal(out, out2), "same seed -> same mask"
+    out3, _, _ = K.add_ln_fwd(x, res, g, b, p_drop=p, seed=99)
+    assert not torch.equal(out, out3)
+
+
+@pytest.mark.parametrize("D", [768, 1024])
+def test_embed_ln(K, D):
+    B, T, V = 3, 40, 1000
+    gen = torch.Generator().manual_seed(0)
+    ids = torch.randint(0, V, (B, T), generator=gen).cuda(); ids[0, -5:] = 1
+    emb = rnd(V, D, scale=0.5, seed=1); pos = rnd(T + 2, D, scale=0.5, seed=2)
+    g = rnd(D, dtype=torch.float32, seed=3) * 0.1 + 1.0; b = rnd(D, dtype=torch.float32, seed=4) * 0.1
+    out, mean, rstd = K.embed_ln_fwd(ids, emb, pos, g, b, embed_scale=1.0)
+    ef = emb.float().requires_grad_(True); pf = pos.float().requires_grad_(True)
+    gf = g.clone().requires_grad_(True); bf = b.clone().requires_grad_(True)
+    h = torch.nn.functional.embedding(ids, ef, padding_idx=1) + pf[2:2 + T][None]
+    ref = torch.nn.functional.layer_norm(h, (D,), gf, bf, 1e-5)
+    close(out, ref, 1e-2, 1e-2, "embed_ln fwd")
+    dout = rnd(B, T, D, seed=5)
+    ref.backward(dout.float())
+    de = torch.zeros(V, D, device="cuda"); dp = torch.zeros(T + 2, D, device="cuda")
+    dg = torch.zeros(D, device="cuda"); db = torch.zeros(D, device="cuda")
+    K.embed_ln_bwd(ids, emb, pos, dout, g, mean, rstd, de, dp, dg, db, padding_idx=1)
+    close(de, ef.grad, 2e-2, 2e-2, "dembed (padding_idx row gets no grad)")
+    close(dp, pf.grad, 2e-2, 3e-2, "dpos"); close(dg, gf.grad, 2e-2, 0.1, "dgamma"); close(db, bf.grad, 2e-2, 0.1, "dbeta")
+
+
+def test_name_embed_mean(K):
+    B, Nn, Ln, V, D = 2, 5, 8, 500, 1024
+    ids = torch.randint(0, V, (B, Nn, Ln), generator=torch.Generator().manual_seed(0)).cuda()
+    emb = rnd(V, D, scale=0.5, seed=1); pos = rnd(Ln + 2, D, scale=0.5, seed=2)
+    g = rnd(D, dtype=torch.float32, seed=3) * 0.1 + 1.0; b = rnd(D, dtype=torch.float32, seed=4) * 0.1
+    out = K.name_embed_mean(ids, emb, pos, g, b)
+    h = emb.float()[ids] + pos.float()[2:2 + Ln][None, None]
+    ref = torch.nn.functional.layer_norm(h, (D,), g, b, 1e-5).mean(2)
+    close(out, ref, 1e-3, 1e-3, "name embed mean")
+
+
+# ------------------------------------------------------------------------------------------------ losses
+@pytest.mark.parametrize("f32", [False, True])
+def test_cross_entropy(K, f32):
+    R, V, ld = 50, 50267, 50272
+    logits = torch.zeros(R, ld, device="cuda", dtype=torch.float32 if f32 else torch.bfloat16)
+    logits[:, :V] = rnd(R, V, scale=2.0, seed=1).to(logits.dtype)
+    logits[:, V:] = 100.0                      # padding columns must be ignored
+    tgt = torch.randint(0, V, (R,), generator=torch.Generator().manual_seed(2)).cuda(); tgt[::7] = 1
+    lse, acc = K.ce_fwd(logits, tgt, V, ignore_index=1)
+    lf = logits[:, :V].float().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(lf, tgt, ignore_index=1)
+    got = (acc[0] / acc[1]).item()
+    assert abs(got - ref.item()) < 2e-3 * abs(ref.item()), (got, ref.item())
+    assert acc[1].item() == (tgt != 1).sum().item()
+    ref.backward()
+    dl = torch.empty(R, ld, device="cuda", dtype=torch.bfloat16)
+    K.ce_bwd(logits, tgt, V, lse, acc, dl)
+    close(dl[:, :V], lf.grad, 2e-2, 1e-5, "dlogits")
+    assert (dl[:, V:] == 0).all()
+
+
+def test_colam(K):
+    B, T, D = 6, 16, 1024
+    hs = rnd(B, T, D, seed=1); hg = rnd(B, T, D, seed=2)
+    hg[0] = hs[0]                               # cos = 1 -> inside the margin only if margin > 1... exercise both sides
+    mask = (torch.arange(T)[None, :] < torch.tensor([16, 3, 9, 1, 12, 5])[:, None]).to(torch.uint8).cuda()
+    for margin in (1.0, 0.05):
+        loss, cos, ps, pg = K.colam_fwd(hs, hg, mask, margin)
+        hf = hs.float().requires_grad_(True)
+        def pool(h):
+            m = mask.bool()
+            e = h.masked_fill(~m[..., None], 0.0).sum(1) / m.sum(1)[..., None]
+            return torch.nan_to_num(e, nan=1.0)
+        a = pool(hf); bb = pool(hg.float())
+        a = a / a.norm(dim=1, keepdim=True); bb = bb / bb.norm(dim=1, keepdim=True)
+        ref = torch.nn.HingeEmbeddingLoss(margin=margin)((a @ bb.t()).diag(), -torch.ones(B, device="cuda"))
+        assert abs(loss.item() - ref.item()) < 1e-4, (loss.item(), ref.item())
+        ref.backward()
+        g = torch.tensor(1.0, device="cuda")
+        dhs = K.colam_bwd(cos, ps, pg, mask, (B, T, D), margin, g, 0.5)
+        close(dhs, 0.5 * hf.grad, 2e-2, 1e-6, f"colam bwd margin={margin}")
+
+
+def test_secla(K):
+    B, F, N, D = 8, 4, 6, 1024
+    faces = rnd(B, F, D, seed=1); names = rnd(B, N, D, dtype=torch.float32, seed=2)
+    loss, sim, l1, l2 = K.secla_fwd(faces, names)
+    ff = faces.float().requires_grad_(True)
+    def batch_softmax(m):
+        bs, _, ns, _ = m.shape
+        logits = m.max(-1).values.sum(-1) / ns
+        return torch.nn.functional.cross_entropy(logits, torch.arange(bs, device=m.device))
+    m1 = torch.matmul(names.unsqueeze(1), ff.permute(0, 2, 1)); m2 = torch.matmul(ff.unsqueeze(1), names.permute(0, 2, 1))
+    ref = batch_softmax(m1) + batch_softmax(m2)
+    assert abs(loss.item() - ref.item()) < 1e-3 * max(1.0, abs(ref.item())), (loss.item(), ref.item())
+    ref.backward()
+    g = torch.tensor(2.0, device="cuda")
+    df = K.secla_bwd(faces, names, sim, l1, l2, g, 1.0)
+    close(df, 2.0 * ff.grad, 2e-2, 1e-4, "secla bwd")
+
+
+# ------------------------------------------------------------------------------------------------- optim
+def test_adamw_and_schedule(K):
+    n = 4096 + 8
+    p = rnd(n, dtype=torch.float32, seed=1); g = rnd(n, dtype=torch.float32, seed=2)
+    m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda"); p16 = torch.empty(n, device="cuda", dtype=torch.bfloat16)
+    hyper = torch.zeros(2, device="cuda")
+    ref_p = torch.nn.Parameter(p.clone())
+    opt = torch.optim.AdamW([ref_p], lr=3e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    total, warm = 100.0, 5.0
+    lam = lambda k: k / max(1.0, warm) if k < warm else max(0.0, (total - k) / max(1.0, total - warm))
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lam)
+    for step in range(8):
+        gg = g * (1.0 + 0.1 * step)
+        ref_p.grad = gg.clone()
+        opt.step(); sched.step()
+        gbuf = gg.clone()
+        K.lr_step(hyper, 3e-5, warm, total)
+        K.adamw(p, gbuf, m, v, p16, hyper, n)
+        assert (gbuf == 0).all()
+    close(p, ref_p.data, 1e-5, 1e-7, "adamw params after 8 steps")
+    close(p16, p, 4e-3, 1e-6, "bf16 shadow")
+    assert hyper[1].item() == 8.0
+
+
+# -------------------------------------------------------------------------------------------------- misc
+def test_misc(K):
+    ids = torch.tensor([[0, 5, 6, 2, 1], [0, 9, 2, 1, 1]], device="cuda")
+    mask, sh = K.prep_ids(ids, pad_id=1, start_id=2)
+    assert mask.tolist() == [[1, 1, 1, 1, 0], [1, 1, 1, 0, 0]]
+    assert sh.tolist() == [[2, 0, 5, 6, 2], [2, 0, 9, 2, 1]]
+    a = rnd(2, 5, 64, seed=1); b = rnd(2, 3, 64, seed=2)
+    assert torch.equal(K.cat_tokens([a, b]), torch.cat([a, b], 1))
+    assert torch.equal(K.add(a, a), (a.float() * 2).bfloat16())
+    lg = rnd(7, 1000, seed=3); lg[2, 10] = 50; lg[2, 900] = 50
+    am = K.argmax_rows(lg, 1000)
+    assert torch.equal(am, lg.float().argmax(-1)) and am[2].item() == 10
+    dy = rnd(300, 520, seed=4); dbias = torch.ones(520, device="cuda")
+    K.bias_grad(dy, dbias, 300, 520)
+    close(dbias, 1.0 + dy.float().sum(0), 1e-3, 1e-2, "bias grad")
+    img = rnd(2, 3, 28, 28, dtype=torch.float32, seed=5)
+    pt = K.im2col_patches(img, 14, 592)
+    ref = torch.nn.functional.unfold(img, 14, stride=14).transpose(1, 2).reshape(2 * 4, 588)
+    close(pt[:, :588], ref, 1e-2, 1e-2, "im2col"); assert (pt[:, 588:] == 0).all()
+    face = torch.ones(2, 3, 512, device="cuda"); face[0, 0] = 0.3
+    assert K.face_mask(face).tolist() == [[1, 0, 0], [0, 0, 0]]
+    x32 = rnd(1000, dtype=torch.float32, seed=6)
+    assert torch.equal(K.cast_f32_bf16(x32), x32.bfloat16())

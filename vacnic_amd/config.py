@@ -1,0 +1,87 @@
+"""Shape/config objects for the VACNIC path (mirrors the BartConfig fields + ctor kwargs the
+reference passes at TRAIN:743 and the CLIP geometry of clip.load, TRAIN:737)."""
+from dataclasses import dataclass, field
+from typing import List
+
+
+@dataclass
+class VacnicConfig:
+    # BartConfig subset (facebook/bart-base | bart-large)
+    d_model: int = 1024
+    encoder_layers: int = 12
+    decoder_layers: int = 12
+    encoder_attention_heads: int = 16
+    decoder_attention_heads: int = 16
+    encoder_ffn_dim: int = 4096
+    decoder_ffn_dim: int = 4096
+    vocab_size: int = 50267            # 50265 + <ENT>, <NONAME> (TRAIN:753-754)
+    max_position_embeddings: int = 1024
+    pad_token_id: int = 1
+    bos_token_id: int = 0
+    eos_token_id: int = 2
+    decoder_start_token_id: int = 2
+    scale_embedding: bool = False
+    activation_function: str = "gelu"
+    dropout: float = 0.1
+    attention_dropout: float = 0.0
+    activation_dropout: float = 0.0
+    init_std: float = 0.02
+    # VACNIC ctor kwargs (MFULL:1881)
+    enc_fusion_layer: List[int] = field(default_factory=lambda: list(range(12)))
+    dim_common: int = 1024
+    prompt_mlp_type: str = "clipcap"
+    prompt_size: int = 20
+    max_ner_type_len: int = 80
+    max_ner_type_len_gt: int = 20
+    only_image: bool = False
+    face_dim: int = 512
+    clip_width: int = 768              # input dim of the ClipCap MLP (hard-coded 768 at MFULL:1136; 1024 for ViT-L/14)
+
+    @property
+    def head_dim(self):
+        return self.d_model // self.encoder_attention_heads
+
+    def validate(self):
+        if self.d_model not in (768, 1024):
+            raise ValueError("d_model must be 768 or 1024 (prompt is reshaped to [B,P,768], MFULL:1143-1144,1275-1278)")
+        if self.d_model % self.encoder_attention_heads or self.d_model // self.encoder_attention_heads != 64:
+            raise ValueError("head_dim must be 64 (bart-base 768/12, bart-large 1024/16)")
+        if self.prompt_mlp_type != "clipcap":
+            raise NotImplementedError("--prompt_mlp_type mlp (MFULL:76-108) is out of scope (SURVEY §2 row 19)")
+        if not self.only_image and self.dim_common != self.d_model:
+            raise ValueError("dim_common must equal d_model: face states are concatenated with name states (MFULL:668)")
+        return self
+
+
+@dataclass
+class ClipVisionConfig:
+    width: int = 1024
+    layers: int = 24
+    patch_size: int = 14
+    image_size: int = 224
+    output_dim: int = 768
+
+    @property
+    def heads(self):
+        return self.width // 64
+
+    @property
+    def grid(self):
+        return self.image_size // self.patch_size
+
+    @property
+    def tokens(self):
+        return self.grid * self.grid + 1
+
+
+def bart_large_vit_l14(**kw):
+    """BASELINE.json configs[1..2]: BART-large + CLIP ViT-L/14, full VACNIC."""
+    return VacnicConfig(clip_width=1024, **kw).validate(), ClipVisionConfig()
+
+
+def bart_base_vit_b32(**kw):
+    """BASELINE.json configs[0]: BART-base + ViT-B/32 --only_image."""
+    c = VacnicConfig(d_model=768, encoder_layers=6, decoder_layers=6, encoder_attention_heads=12,
+                     decoder_attention_heads=12, encoder_ffn_dim=3072, decoder_ffn_dim=3072,
+                     enc_fusion_layer=list(range(6)), dim_common=768, only_image=True, clip_width=768, **kw).validate()
+    return c, ClipVisionConfig(width=768, layers=12, patch_size=32, output_dim=512)

@@ -1,0 +1,308 @@
+"""Thin, non-autograd wrappers: torch tensors in, raw device pointers through the C-ABI.
+
+PyTorch here is plumbing only (device memory + the current HIP stream); every arithmetic op on the
+path is a hand-written gfx950 kernel in libvacnic_hip.so.  All wrappers launch on
+`torch.cuda.current_stream()` so they are hipGraph-capturable, and all fail loudly on CPU tensors.
+"""
+import torch
+
+from . import _lib
+from ._lib import call, call_struct
+
+ACT = {None: 0, "none": 0, "gelu": 1, "tanh": 2, "quick_gelu": 3}
+BF16 = torch.bfloat16
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("vacnic_amd kernels need CUDA/HIP tensors (there is no CPU fallback)")
+    return t.data_ptr()
+
+
+def _row_stride(t):
+    """t is [..., rows, cols] with unit inner stride and uniformly strided rows when flattened."""
+    assert t.stride(-1) == 1, "inner dimension must be contiguous"
+    return t.stride(-2) if t.dim() >= 2 else t.shape[-1]
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def gemm(x, w, M, N, K, *, bias=None, out=None, ldx=None, ldw=None, ldo=None, x_kstrided=False, w_kstrided=False,
+         act=None, out_mode=0, split_k=1, alpha=1.0, preact=None, dact_src=None, residual=None):
+    """out[m][n] = epi(alpha * sum_k X(m,k) W(n,k) + bias[n]) — see include/vacnic_hip.h."""
+    if out is None:
+        out = torch.empty((M, N), device=x.device, dtype=BF16 if out_mode == 0 else torch.float32)
+    ldx = ldx if ldx is not None else (M if x_kstrided else K)
+    ldw = ldw if ldw is not None else (N if w_kstrided else K)
+    ldo = ldo if ldo is not None else N
+    call_struct("vacnic_gemm_bf16", stream=_stream(), x=_p(x), w=_p(w), bias=_p(bias), out=_p(out), preact=_p(preact),
+                dact_src=_p(dact_src), residual=_p(residual), M=M, N=N, K=K, ldx=ldx, ldw=ldw, ldo=ldo,
+                x_kstrided=int(x_kstrided), w_kstrided=int(w_kstrided), act=ACT[act], out_mode=out_mode,
+                split_k=split_k, alpha=alpha)
+    return out
+
+
+def wgrad_split(M_red, n_tiles):
+    """split-K factor for a weight gradient whose reduction runs over M_red rows: aim at >= 512 workgroups."""
+    s = 1
+    while n_tiles * s < 512 and M_red // (s * 2) >= 512 and s < 16:
+        s *= 2
+    return s
+
+
+# ------------------------------------------------------------------------------------------- attention
+def attn_fwd(q, k, v, B, H, Tq, Tk, key_mask=None, causal=False, scale=0.125, need_lse=True):
+    """q/k/v: [B, T, >=H*64] views (unit inner stride); returns out [B,Tq,H*64] bf16 and lse [B,H,Tq]."""
+    out = torch.empty((B, Tq, H * 64), device=q.device, dtype=BF16)
+    lse = torch.empty((B, H, Tq), device=q.device, dtype=torch.float32) if need_lse else None
+    call_struct("vacnic_attn_fwd", stream=_stream(), q=_p(q), k=_p(k), v=_p(v), out=_p(out), lse=_p(lse),
+                key_mask=_p(key_mask), B=B, H=H, Tq=Tq, Tk=Tk, ldq=q.stride(1), ldk=k.stride(1), ldv=v.stride(1),
+                ldo=out.stride(1), bsq=q.stride(0), bsk=k.stride(0), bsv=v.stride(0), bso=out.stride(0),
+                causal=int(causal), scale=scale)
+    return out, lse
+
+
+def attn_bwd(q, k, v, out, dout, lse, dq, dk, dv, B, H, Tq, Tk, key_mask=None, causal=False, scale=0.125):
+    delta = torch.empty((B, H, Tq), device=q.device, dtype=torch.float32)
+    assert dout.stride() == out.stride()
+    call_struct("vacnic_attn_bwd", stream=_stream(), q=_p(q), k=_p(k), v=_p(v), out=_p(out), dout=_p(dout), lse=_p(lse),
+                delta=_p(delta), dq=_p(dq), dk=_p(dk), dv=_p(dv), key_mask=_p(key_mask), B=B, H=H, Tq=Tq, Tk=Tk,
+                ldq=q.stride(1), ldk=k.stride(1), ldv=v.stride(1), ldo=out.stride(1),
+                bsq=q.stride(0), bsk=k.stride(0), bsv=v.stride(0), bso=out.stride(0),
+                lddq=dq.stride(1), lddk=dk.stride(1), lddv=dv.stride(1),
+                bsdq=dq.stride(0), bsdk=dk.stride(0), bsdv=dv.stride(0), causal=int(causal), scale=scale)
+
+
+# -------------------------------------------------------------------------------------------- LN family
+def add_ln_fwd(x, residual, gamma, beta, eps=1e-5, p_drop=0.0, seed=0, need_stats=True):
+    D = x.shape[-1]
+    R = x.numel() // D
+    out = torch.empty_like(x)
+    mean = torch.empty(R, device=x.device, dtype=torch.float32) if need_stats else None
+    rstd = torch.empty(R, device=x.device, dtype=torch.float32) if need_stats else None
+    call_struct("vacnic_add_ln_fwd", stream=_stream(), x=_p(x), residual=_p(residual), gamma=_p(gamma), beta=_p(beta),
+                out=_p(out), mean=_p(mean), rstd=_p(rstd), R=R, D=D, eps=eps, p_drop=p_drop, seed=seed)
+    return out, mean, rstd
+
+
+def add_ln_bwd(dout, x, residual, gamma, mean, rstd, dgamma, dbeta, p_drop=0.0, seed=0, need_dres=True):
+    D = x.shape[-1]
+    R = x.numel() // D
+    dx = torch.empty_like(x)
+    if residual is None or not need_dres:
+        dres = None
+    elif p_drop > 0.0:
+        dres = torch.empty_like(x)
+    else:
+        dres = None            # identical to dx: caller reuses dx
+    call_struct("vacnic_add_ln_bwd", stream=_stream(), dout=_p(dout), x=_p(x), residual=_p(residual), gamma=_p(gamma),
+                mean=_p(mean), rstd=_p(rstd), dresidual=_p(dres), dx=_p(dx), dgamma=_p(dgamma), dbeta=_p(dbeta),
+                R=R, D=D, p_drop=p_drop, seed=seed)
+    return dx, (dres if dres is not None else dx)
+
+
+def embed_ln_fwd(ids, embed16, pos16, gamma, beta, embed_scale=1.0, pos_offset=2, eps=1e-5, p_drop=0.0, seed=0):
+    B, T = ids.shape
+    V, D = embed16.shape
+    out = torch.empty((B, T, D), device=ids.device, dtype=BF16)
+    mean = torch.empty(B * T, device=ids.device, dtype=torch.float32)
+    rstd = torch.empty(B * T, device=ids.device, dtype=torch.float32)
+    call_struct("vacnic_embed_ln_fwd", stream=_stream(), ids=_p(ids), embed=_p(embed16), pos=_p(pos16), gamma=_p(gamma),
+                beta=_p(beta), out=_p(out), mean=_p(mean), rstd=_p(rstd), B=B, T=T, D=D, V=V, pos_offset=pos_offset,
+                embed_scale=embed_scale, eps=eps, p_drop=p_drop, seed=seed)
+    return out, mean, rstd
+
+
+def embed_ln_bwd(ids, embed16, pos16, dout, gamma, mean, rstd, dembed, dpos, dgamma, dbeta, embed_scale=1.0,
+                 pos_offset=2, padding_idx=1, p_drop=0.0, seed=0):
+    B, T = ids.shape
+    V, D = embed16.shape
+    call_struct("vacnic_embed_ln_bwd", stream=_stream(), ids=_p(ids), embed=_p(embed16), pos=_p(pos16), dout=_p(dout),
+                gamma=_p(gamma), mean=_p(mean), rstd=_p(rstd), dembed=_p(dembed), dpos=_p(dpos), dgamma=_p(dgamma),
+                dbeta=_p(dbeta), B=B, T=T, D=D, V=V, pos_offset=pos_offset, embed_scale=embed_scale,
+                padding_idx=padding_idx, p_drop=p_drop, seed=seed)
+
+
+def name_embed_mean(ids3d, embed16, pos16, gamma, beta, embed_scale=1.0, pos_offset=2, eps=1e-5):
+    B, Nn, Ln = ids3d.shape
+    V, D = embed16.shape
+    out = torch.empty((B, Nn, D), device=ids3d.device, dtype=torch.float32)
+    call_struct("vacnic_name_embed_mean", stream=_stream(), ids=_p(ids3d), embed=_p(embed16), pos=_p(pos16),
+                gamma=_p(gamma), beta=_p(beta), out=_p(out), B=B, Nn=Nn, Ln=Ln, D=D, V=V, pos_offset=pos_offset,
+                embed_scale=embed_scale, eps=eps)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ losses
+def ce_fwd(logits, targets, V, ignore_index=1):
+    R, ldl = logits.shape[0], logits.stride(0)
+    dev = logits.device
+    row_lse = torch.empty(R, device=dev, dtype=torch.float32)
+    acc = torch.zeros(2, device=dev, dtype=torch.float32)       # {loss_sum, count}
+    call_struct("vacnic_ce_fwd", stream=_stream(), logits=_p(logits), targets=_p(targets), row_lse=_p(row_lse),
+                row_loss=None, loss_sum=acc.data_ptr(), count=acc.data_ptr() + 4, dlogits=None, grad_out=None,
+                grad_scale=1.0, R=R, V=V, ldl=ldl, ldd=ldl, ignore_index=ignore_index,
+                logits_f32=int(logits.dtype == torch.float32))
+    return row_lse, acc
+
+
+def ce_bwd(logits, targets, V, row_lse, acc, dlogits, grad_out=None, grad_scale=1.0, ignore_index=1):
+    R, ldl = logits.shape[0], logits.stride(0)
+    call_struct("vacnic_ce_bwd", stream=_stream(), logits=_p(logits), targets=_p(targets), row_lse=_p(row_lse),
+                row_loss=None, loss_sum=acc.data_ptr(), count=acc.data_ptr() + 4, dlogits=_p(dlogits),
+                grad_out=_p(grad_out), grad_scale=grad_scale, R=R, V=V, ldl=ldl, ldd=dlogits.stride(0),
+                ignore_index=ignore_index, logits_f32=int(logits.dtype == torch.float32))
+
+
+def combine_losses(ce_sum_ptr, count_ptr, secla, colam, w_secla, w_colam, device):
+    out4 = torch.empty(4, device=device, dtype=torch.float32)
+    call("vacnic_combine_losses", ce_sum_ptr, count_ptr, _p(secla), _p(colam), w_secla, w_colam, out4.data_ptr(), _stream())
+    return out4
+
+
+def colam_fwd(hs, hg, mask_u8, margin):
+    B, T, D = hs.shape
+    dev = hs.device
+    loss = torch.empty((), device=dev, dtype=torch.float32)
+    cos = torch.empty(B, device=dev, dtype=torch.float32)
+    ps = torch.empty((B, D), device=dev, dtype=torch.float32)
+    pg = torch.empty((B, D), device=dev, dtype=torch.float32)
+    call_struct("vacnic_colam_fwd", stream=_stream(), hs=_p(hs), hg=_p(hg), mask=_p(mask_u8), loss=_p(loss), cos=_p(cos),
+                pooled_s=_p(ps), pooled_g=_p(pg), B=B, T=T, D=D, margin=margin)
+    return loss, cos, ps, pg
+
+
+def colam_bwd(cos, ps, pg, mask_u8, shape, margin, grad_out, grad_scale):
+    B, T, D = shape
+    dhs = torch.empty(shape, device=cos.device, dtype=BF16)
+    call_struct("vacnic_colam_bwd", stream=_stream(), cos=_p(cos), pooled_s=_p(ps), pooled_g=_p(pg), mask=_p(mask_u8),
+                dhs=_p(dhs), B=B, T=T, D=D, margin=margin, grad_out=_p(grad_out), grad_scale=grad_scale)
+    return dhs
+
+
+def secla_fwd(faces, names):
+    B, F, D = faces.shape
+    N = names.shape[1]
+    dev = faces.device
+    sim = torch.empty((B, N, B, F), device=dev, dtype=torch.float32)
+    l1 = torch.empty((B, B), device=dev, dtype=torch.float32)
+    l2 = torch.empty((B, B), device=dev, dtype=torch.float32)
+    loss = torch.empty((), device=dev, dtype=torch.float32)
+    call_struct("vacnic_secla_fwd", stream=_stream(), faces=_p(faces), names=_p(names), sim=_p(sim), logits1=_p(l1),
+                logits2=_p(l2), loss=_p(loss), B=B, F=F, N=N, D=D)
+    return loss, sim, l1, l2
+
+
+def secla_bwd(faces, names, sim, l1, l2, grad_out, grad_scale):
+    B, F, D = faces.shape
+    N = names.shape[1]
+    dfaces = torch.empty((B, F, D), device=faces.device, dtype=BF16)
+    wsim = torch.empty_like(sim)
+    call_struct("vacnic_secla_bwd", stream=_stream(), faces=_p(faces), names=_p(names), sim=_p(sim), logits1=_p(l1),
+                logits2=_p(l2), dfaces=_p(dfaces), wsim=_p(wsim), B=B, F=F, N=N, D=D, grad_out=_p(grad_out),
+                grad_scale=grad_scale)
+    return dfaces
+
+
+# ---------------------------------------------------------------------------------------------- optimizer
+def lr_step(hyper, base_lr, warmup, total):
+    call("vacnic_lr_step", hyper.data_ptr(), base_lr, float(warmup), float(total), _stream())
+
+
+def adamw(p, g, m, v, p16, hyper, n, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, grad_scale=1.0, zero_grad=True):
+    call_struct("vacnic_adamw", stream=_stream(), p=_p(p), g=_p(g), m=_p(m), v=_p(v), p_bf16=_p(p16), hyper=_p(hyper),
+                n=n, beta1=beta1, beta2=beta2, eps=eps, weight_decay=weight_decay, grad_scale=grad_scale,
+                zero_grad=int(zero_grad))
+
+
+# ------------------------------------------------------------------------------------------------- misc
+def cast_f32_bf16(src, dst=None):
+    if dst is None:
+        dst = torch.empty(src.shape, device=src.device, dtype=BF16)
+    assert src.is_contiguous() and dst.is_contiguous()
+    call("vacnic_cast_f32_bf16", _p(src), _p(dst), src.numel(), _stream())
+    return dst
+
+
+def cast_bf16_f32(src):
+    dst = torch.empty(src.shape, device=src.device, dtype=torch.float32)
+    assert src.is_contiguous()
+    call("vacnic_cast_bf16_f32", _p(src), _p(dst), src.numel(), _stream())
+    return dst
+
+
+def copy3d(src, dst, B, rows, cols, accumulate=False):
+    """src/dst: [B, rows, cols] views with unit inner stride."""
+    call("vacnic_copy3d_bf16", _p(src), _p(dst), B, rows, cols, src.stride(1), dst.stride(1), src.stride(0), dst.stride(0),
+         int(accumulate), _stream())
+
+
+def cat_tokens(parts):
+    """torch.cat(parts, dim=1) for [B, T_i, D] bf16 tensors (MFULL:666,691)."""
+    B, _, D = parts[0].shape
+    T = sum(p.shape[1] for p in parts)
+    out = torch.empty((B, T, D), device=parts[0].device, dtype=BF16)
+    o = 0
+    for p in parts:
+        copy3d(p, out[:, o:o + p.shape[1]], B, p.shape[1], D)
+        o += p.shape[1]
+    return out
+
+
+def add(a, b):
+    out = torch.empty_like(a)
+    assert a.is_contiguous() and b.is_contiguous()
+    call("vacnic_add_bf16", _p(a), _p(b), _p(out), a.numel(), _stream())
+    return out
+
+
+def im2col_patches(img, patch, Kp):
+    B, _, HW, _ = img.shape
+    g = HW // patch
+    out = torch.empty((B * g * g, Kp), device=img.device, dtype=BF16)
+    call("vacnic_im2col_patches", _p(img), _p(out), B, HW, patch, Kp, _stream())
+    return out
+
+
+def vit_assemble(patch_emb, cls16, pos16, B, G2, W):
+    out = torch.empty((B, G2 + 1, W), device=patch_emb.device, dtype=BF16)
+    call("vacnic_vit_assemble", _p(patch_emb), _p(cls16), _p(pos16), _p(out), B, G2, W, _stream())
+    return out
+
+
+def prep_ids(ids, pad_id=1, start_id=None, want_mask=True):
+    B, T = ids.shape
+    mask = torch.empty((B, T), device=ids.device, dtype=torch.uint8) if want_mask else None
+    shifted = torch.empty_like(ids) if start_id is not None else None
+    call("vacnic_prep_ids", _p(ids), _p(mask), _p(shifted), B, T, pad_id, start_id if start_id is not None else 0, _stream())
+    return mask, shifted
+
+
+def face_mask(face_emb):
+    B, F, D = face_emb.shape
+    mask = torch.empty((B, F), device=face_emb.device, dtype=torch.uint8)
+    call("vacnic_face_mask", _p(face_emb), _p(mask), B * F, D, _stream())
+    return mask
+
+
+def argmax_rows(logits, V):
+    R = logits.shape[0]
+    out = torch.empty(R, device=logits.device, dtype=torch.int64)
+    call("vacnic_argmax_rows", _p(logits), _p(out), R, V, logits.stride(0), int(logits.dtype == torch.float32), _stream())
+    return out
+
+
+def bias_grad(dy2d, dbias, M, N):
+    call("vacnic_bias_grad", _p(dy2d), _p(dbias), M, N, dy2d.stride(0), _stream())
+
+
+def probe_layouts():
+    out = torch.zeros(2624, device="cuda", dtype=torch.float32)
+    src = torch.arange(128, device="cuda", dtype=torch.float32) + 1.0
+    call("vacnic_probe_layouts", _p(out), _p(src), out.numel(), _stream())
+    return out
