@@ -1,0 +1,207 @@
+"""bench.py — VACNIC train-step throughput on MI355X (BASELINE.json metric: train samples/sec,
+BART-large + CLIP ViT-L/14, GoodNews-shaped batch; config.workload names configs[1]/[2]).
+
+    python bench.py --gpus 1 --steps 8 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one full training step on one synthetic batch already resident in HBM: ViT-L/14 features,
+multimodal BART-large forward (+ fused LM-head/CE), frozen guide BART forward, CoLaM + SECLA losses,
+backward, gradient all-reduce (N > 1), fused AdamW + LR schedule.  Nothing is skipped or cached.
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak, MI355X_MICROARCH.md
+STEP_GFLOP_PER_SAMPLE = {512: 1179.8, 1024: 2142.7}      # SURVEY §8d (3*F_t + F_g + F_v)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE: 32)")
+    ap.add_argument("--seq", type=int, default=512, help="article tokens S")
+    ap.add_argument("--cap", type=int, default=64, help="caption tokens T")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=2)
+    return ap.parse_args()
+
+
+class GemmTimer:
+    """HIP events around every GEMM launch of ONE timed step, on the stream the kernels are launched on."""
+
+    def __init__(self):
+        self.rec = []
+
+    def install(self):
+        from vacnic_amd import kernels as K
+        self.orig = K.gemm
+        timer = self
+
+        def timed(x, w, M, N, Kd, **kw):
+            s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = timer.orig(x, w, M, N, Kd, **kw)
+            e.record()
+            kind = ("T" if kw.get("x_kstrided") else "N") + ("T" if kw.get("w_kstrided") else "N")
+            timer.rec.append((kind, 2.0 * M * N * Kd, s, e))
+            return out
+        K.gemm = timed
+
+    def remove(self):
+        from vacnic_amd import kernels as K
+        K.gemm = self.orig
+
+    def summary(self):
+        agg = {}
+        for kind, fl, s, e in self.rec:
+            a = agg.setdefault(kind, [0.0, 0.0, 0])
+            a[0] += fl; a[1] += s.elapsed_time(e) * 1e-3; a[2] += 1
+        return agg
+
+
+def cpu_baseline(cfg, vcfg, B, S, T):
+    """The oracle (CPU restatement, torch fp32 + autograd) timed on this box's host cores: fwd + bwd + AdamW of the
+    same step at the same shapes, reduced batch.  Reported beside the GPU number, never the target."""
+    from oracle import vacnic_oracle as O
+    from vacnic_amd import synthetic
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(0)
+
+    def rand_sd(shapes):
+        return {k: (torch.randn(v, generator=g) * 0.02 if len(v) > 1 else (torch.ones(v) if k.endswith("weight") else torch.zeros(v)))
+                for k, v in shapes.items()}
+    sd = rand_sd(synthetic.mmbart_param_shapes(cfg))
+    sd_g = rand_sd(synthetic.guide_bart_param_shapes(cfg))
+    sd_c = rand_sd(synthetic.clip_visual_param_shapes(vcfg))
+    for v in sd.values():
+        v.requires_grad_(True)
+    batch = synthetic.make_batch(cfg, B, S=S, T=T, seed=1, full_length=True)
+    m = {k: torch.zeros_like(v) for k, v in sd.items()}
+    vv = {k: torch.zeros_like(v) for k, v in sd.items()}
+
+    def step(i):
+        res = O.train_losses(sd, sd_g, sd_c, cfg, vcfg, batch)
+        res["loss"].backward()
+        with torch.no_grad():
+            for k, p in sd.items():
+                if p.grad is None:
+                    continue
+                np_, m[k], vv[k] = O.adamw_step(p, p.grad, m[k], vv[k], i + 1, 3e-5)
+                p.copy_(np_); p.grad = None
+    step(0)                                     # warm-up
+    best = 1e30
+    for i in range(2):
+        t0 = time.time(); step(i + 1); best = min(best, time.time() - t0)
+    return {"value": round(B / best, 4), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (torch fp32 CPU) full train step, same model/shapes, batch {B} (S={S}, T={T}), best of 2 after 1 warm-up"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world == 1:
+        raise SystemExit("launch with torch.distributed.run for --gpus > 1 (one process per GPU)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from vacnic_amd import synthetic
+    from vacnic_amd.config import bart_large_vit_l14
+    from vacnic_amd.ddp import DistributedDataParallel
+    from vacnic_amd.training import FusedAdamW, TrainArgs, build_models, to_device, train_step
+
+    cfg, vcfg = bart_large_vit_l14()
+    B, S, T = a.batch, a.seq, a.cap
+    model, guide, _ = build_models(cfg, vcfg, device="cuda", seed=1234, init="device")
+    args = TrainArgs(num_training_steps=100000)
+    net = DistributedDataParallel(model) if world > 1 else model
+    opt = FusedAdamW(model.arena, lr=args.lr_bart, weight_decay=args.weight_decay,
+                     num_warmup_steps=args.warmup_rate * args.num_training_steps, num_training_steps=args.num_training_steps,
+                     world_size=world)
+    nb = 4
+    batches = [to_device(synthetic.make_batch(cfg, B, S=S, T=T, seed=42, rank=rank, step=i, full_length=True), "cuda") for i in range(nb)]
+    torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        train_step(net, guide, opt, batches[i % nb], args)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer = GemmTimer()
+    t0 = time.perf_counter()
+    out4 = None
+    for i in range(a.steps):
+        if i == a.steps - 1:
+            timer.install()
+        out4 = train_step(net, guide, opt, batches[(a.warmup + i) % nb], args)
+    timer.remove()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    losses = out4.tolist()
+    if rank == 0:
+        agg = timer.summary()
+        dom = max(agg.items(), key=lambda kv: kv[1][1]) if agg else None
+        roof = None
+        if dom:
+            kind, (fl, sec, n) = dom
+            ach = fl / sec / 1e12
+            names = {"NN": "gemm_kernel<false,false> (forward Linear, X[M,K] W[N,K])", "NT": "gemm_kernel<false,true> (dgrad)",
+                     "TT": "gemm_kernel<true,true> (wgrad)", "TN": "gemm_kernel<true,false>"}
+            roof = {"bound": "mfma", "kernel": names[kind], "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches": n,
+                    "avg_launch_us": round(sec / n * 1e6, 2),
+                    "all_gemm": {k: {"TFLOP/s": round(v[0] / v[1] / 1e12, 1), "ms": round(v[1] * 1e3, 2), "launches": v[2]} for k, v in agg.items()}}
+        samples = B * world * a.steps
+        value = samples / dt
+        gf = STEP_GFLOP_PER_SAMPLE.get(S)
+        res = {"metric": "train samples/sec, BART-large + CLIP ViT-L/14 full VACNIC step, GoodNews-shaped batch",
+               "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": f"BASELINE configs[{1 if world == 1 else 2}]: BART-large + CLIP ViT-L/14 full VACNIC (clipcap P=20, SECLA, CoLaM a=0.5 m=1.0), "
+                                      f"224x224 image, {S}-token article, {T}-token caption, per-GPU batch {B}, dropout 0.1, fp32 master + bf16 compute",
+                          "global_batch": B * world, "seq_len": S, "caption_len": T, "parallelism": f"dp{world}"},
+               "step_tflops_per_gpu": round(value / world * gf / 1e3, 1) if gf else None,
+               "step_mfma_frac": round(value / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4) if gf else None,
+               "losses_last_step": {"total": losses[0], "txt": losses[1], "secla": losses[2], "colam": losses[3]},
+               "roofline": roof}
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline(cfg, vcfg, a.cpu_batch, S, T)
+            except Exception as e:      # the baseline must never sink the GPU measurement
+                res["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

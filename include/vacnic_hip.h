@@ -17,7 +17,8 @@
  *    no device allocation inside the library.
  *  - return value: 0 = ok, otherwise a vacnic_status; vacnic_last_error_string() has the text.
  *  - bf16 tensors are raw uint16 storage ("bf16"), fp32 tensors "f32"; row strides ("ld*") are in
- *    elements.  bf16 row strides and K must be multiples of 8 (16-byte rows).
+ *    elements.  bf16 row strides must be multiples of 8 (16-byte rows); a K-contiguous GEMM operand
+ *    whose K is not a multiple of 8 must have ld >= round_up(K, 8) with finite padding (zero on one side).
  */
 #ifndef VACNIC_HIP_H
 #define VACNIC_HIP_H
@@ -243,6 +244,9 @@ int vacnic_copy2d_bf16(const void* src, void* dst, int64_t rows, int64_t cols, i
 /* 3-D variant: [B][rows][cols] with batch strides. */
 int vacnic_copy3d_bf16(const void* src, void* dst, int64_t B, int64_t rows, int64_t cols,
                        int64_t lds, int64_t ldd, int64_t bss, int64_t bsd, int32_t accumulate, void* stream);
+/* dst[R][Cp] = src[R][C] zero-padded on the right (C not a multiple of 8: the 20-wide name-prefix FFN output,
+ * MFULL:595) so the following GEMMs see 16-byte rows. */
+int vacnic_pad_cols_bf16(const void* src, void* dst, int64_t R, int64_t C, int64_t Cp, int64_t lds, void* stream);
 /* CLIP patch embedding im2col (conv1 with kernel = stride = patch, no bias; TRAIN:225-227):
  * img f32 [B][3][HW][HW] -> patches bf16 [B*g*g][Kp] (k = c*p*p + py*p + px, zero-padded to Kp). */
 int vacnic_im2col_patches(const float* img, void* patches, int64_t B, int64_t HW, int64_t patch, int64_t Kp,

@@ -124,6 +124,7 @@ _PLAIN_FNS = {
     "vacnic_cast_bf16_f32": [vp, vp, i64, vp],
     "vacnic_copy2d_bf16": [vp, vp, i64, i64, i64, i64, i32, vp],
     "vacnic_copy3d_bf16": [vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, vp],
+    "vacnic_pad_cols_bf16": [vp, vp, i64, i64, i64, i64, vp],
     "vacnic_im2col_patches": [vp, vp, i64, i64, i64, i64, vp],
     "vacnic_vit_assemble": [vp, vp, vp, vp, i64, i64, i64, vp],
     "vacnic_prep_ids": [vp, vp, vp, i64, i64, i64, i64, vp],

@@ -252,8 +252,6 @@ extern "C" int vacnic_gemm_bf16(const vacnic_gemm_args* a, void* stream) {
   VCHECK(a && a->x && a->w && a->out, VACNIC_BAD_SHAPE, "gemm: null operand");
   VCHECK(a->M > 0 && a->N > 0 && a->K > 0, VACNIC_BAD_SHAPE, "gemm: empty problem M=%ld N=%ld K=%ld",
          (long)a->M, (long)a->N, (long)a->K);
-  VCHECK((a->K & 7) == 0 || (a->x_kstrided && a->w_kstrided), VACNIC_BAD_SHAPE,
-         "gemm: K=%ld must be a multiple of 8 for K-contiguous operands", (long)a->K);
   VCHECK((a->ldx & 7) == 0 && (a->ldw & 7) == 0, VACNIC_MISALIGNED, "gemm: ldx/ldw must be multiples of 8");
   VCHECK(aligned16(a->x) && aligned16(a->w), VACNIC_MISALIGNED, "gemm: x/w must be 16-byte aligned");
   VCHECK(a->out_mode >= 0 && a->out_mode <= 2, VACNIC_BAD_DTYPE, "gemm: bad out_mode %d", a->out_mode);
@@ -261,13 +259,14 @@ extern "C" int vacnic_gemm_bf16(const vacnic_gemm_args* a, void* stream) {
   VCHECK(split == 1 || a->out_mode == 2, VACNIC_UNSUPPORTED, "gemm: split_k needs out_mode 2");
   VCHECK(a->ldo >= a->N, VACNIC_BAD_SHAPE, "gemm: ldo < N");
   if (a->x_kstrided) VCHECK(a->ldx >= ((a->M + 7) & ~7LL), VACNIC_BAD_SHAPE, "gemm: ldx too small for K-strided X");
-  else VCHECK(a->ldx >= a->K, VACNIC_BAD_SHAPE, "gemm: ldx < K");
+  else VCHECK(a->ldx >= ((a->K + 7) & ~7LL), VACNIC_BAD_SHAPE, "gemm: ldx < round_up(K, 8) for K-contiguous X");
   if (a->w_kstrided) VCHECK(a->ldw >= ((a->N + 7) & ~7LL), VACNIC_BAD_SHAPE, "gemm: ldw too small for K-strided W");
-  else VCHECK(a->ldw >= a->K, VACNIC_BAD_SHAPE, "gemm: ldw < K");
+  else VCHECK(a->ldw >= ((a->K + 7) & ~7LL), VACNIC_BAD_SHAPE, "gemm: ldw < round_up(K, 8) for K-contiguous W");
 
   auto span = [](int64_t rows, int64_t cols, int64_t ld) { return ((rows - 1) * ld + cols) * 2; };
-  const int64_t xb = a->x_kstrided ? span(a->K, (a->M + 7) & ~7LL, a->ldx) : span(a->M, a->K, a->ldx);
-  const int64_t wb = a->w_kstrided ? span(a->K, (a->N + 7) & ~7LL, a->ldw) : span(a->N, a->K, a->ldw);
+  const int64_t K8 = (a->K + 7) & ~7LL;
+  const int64_t xb = a->x_kstrided ? span(a->K, (a->M + 7) & ~7LL, a->ldx) : span(a->M, K8, a->ldx);
+  const int64_t wb = a->w_kstrided ? span(a->K, (a->N + 7) & ~7LL, a->ldw) : span(a->N, K8, a->ldw);
   VCHECK(xb < 0x7ffffff0LL && wb < 0x7ffffff0LL, VACNIC_UNSUPPORTED, "gemm: operand larger than 2 GiB");
 
   GemmP p;

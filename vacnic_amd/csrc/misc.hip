@@ -46,6 +46,16 @@ __global__ __launch_bounds__(256) void add_kernel(const bf16_t* __restrict__ a, 
   }
 }
 
+// dst[r][0..Cp) = src[r][0..C) then zeros: gives an odd-width activation 16-byte rows for the GEMM
+__global__ __launch_bounds__(256) void pad_cols_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, long R, int C,
+                                                       int Cp, long lds) {
+  const long total = R * Cp;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cp); const long r = i / Cp;
+    dst[i] = c < C ? src[r * lds + c] : (bf16_t)0;
+  }
+}
+
 // patches[(b*g + gy)*g + gx][k], k = c*p*p + py*p + px  (conv1 weight [w][3][p][p] flattened)
 __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, long B, int HW,
                                                      int p, int Kp) {
@@ -174,6 +184,14 @@ extern "C" int vacnic_add_bf16(const void* a, const void* b, void* out, int64_t 
   if (n == 0) return VACNIC_OK;
   hipLaunchKernelGGL(add_kernel, dim3(grid_for(n >> 3)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a,
                      (const bf16_t*)b, (bf16_t*)out, (long)(n >> 3));
+  VLAUNCH_CHECK();
+  return VACNIC_OK;
+}
+extern "C" int vacnic_pad_cols_bf16(const void* src, void* dst, int64_t R, int64_t C, int64_t Cp, int64_t lds, void* stream) {
+  VCHECK(src && dst && Cp >= C && lds >= C, VACNIC_BAD_SHAPE, "pad_cols: bad operand");
+  if (R * Cp == 0) return VACNIC_OK;
+  hipLaunchKernelGGL(pad_cols_kernel, dim3(grid_for(R * Cp)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src,
+                     (bf16_t*)dst, (long)R, (int)C, (int)Cp, (long)lds);
   VLAUNCH_CHECK();
   return VACNIC_OK;
 }

@@ -1,0 +1,134 @@
+"""Data-parallel gradient reduction over RCCL/xGMI — replaces torch.nn.parallel.DistributedDataParallel
+(TRAIN:87, TRAINV:84, DDPINF:1089) for the arena-based model.
+
+One process per GPU (torch.distributed, backend "nccl" == RCCL on ROCm).  The path is pure data
+parallel: the only collectives are a parameter broadcast at construction and one
+SUM all-reduce of the fp32 gradient arena per step; averaging (1/world) is folded into the fused
+AdamW kernel (grad_scale).  Because gradients already live in ONE flat buffer there is no
+flatten/unflatten: buckets are contiguous slices.
+
+Overlap with backward is exact, not heuristic: every op that will accumulate into a gradient slice
+registers a pending write in forward (GradTracker.expect) and retires it in backward right after it
+has enqueued its wgrad kernel (GradTracker.done).  When the pending count of a bucket reaches zero
+the reducer records an event on the compute stream, makes the comm stream wait for it, and launches
+that bucket's all-reduce there — large buckets (default 256 MiB: xGMI is point-to-point, 7 links per
+GPU, so few large collectives beat many 25 MiB ones) in the order backward completes them.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradTracker:
+    """Per-bucket count of gradient writes still outstanding in the current backward."""
+
+    def __init__(self, arena, bucket_bytes=256 << 20):
+        self.arena = arena
+        self.base = arena.grad.data_ptr()
+        self.buckets = arena.bucket_slices(bucket_bytes)        # reverse layout order
+        self.starts = sorted(s for s, _ in self.buckets)
+        self.pending = {s: 0 for s in self.starts}
+        self.on_ready = None
+        self.in_backward = False
+
+    def _bucket_of(self, t):
+        import bisect
+        off = (t.data_ptr() - self.base) // 4
+        lo = self.starts[bisect.bisect_right(self.starts, off) - 1]
+        hi_off = off + t.numel() - 1
+        hi = self.starts[bisect.bisect_right(self.starts, hi_off) - 1]
+        return [s for s in self.starts if lo <= s <= hi]
+
+    def expect(self, t):
+        if t is None:
+            return
+        for s in self._bucket_of(t):
+            self.pending[s] += 1
+
+    def done(self, t):
+        if t is None:
+            return
+        for s in self._bucket_of(t):
+            self.pending[s] -= 1
+            if self.pending[s] == 0 and self.on_ready is not None:
+                self.on_ready(s)
+
+    def reset(self):
+        for s in self.pending:
+            self.pending[s] = 0
+
+
+TRACKER = None        # set by DistributedDataParallel when world_size > 1; ops.py consults it
+
+
+def expect(need_grad, *tensors):
+    """called from Function.forward (grad mode is off there, so the caller passes any(ctx.needs_input_grad))."""
+    if TRACKER is not None and need_grad:
+        for t in tensors:
+            TRACKER.expect(t)
+
+
+def done(*tensors):
+    if TRACKER is not None:
+        for t in tensors:
+            TRACKER.done(t)
+
+
+class DistributedDataParallel(torch.nn.Module):
+    """DDP-shaped wrapper: `.module`, forward passthrough; call `reduce_gradients()` after backward()
+    (or use `vacnic_amd.training.train_step`, which does).  With world_size 1 it is a no-op shell."""
+
+    def __init__(self, module, device_ids=None, output_device=None, process_group=None, bucket_bytes=256 << 20,
+                 overlap=True):
+        super().__init__()
+        global TRACKER
+        self.module = module
+        self.pg = process_group
+        self.world = dist.get_world_size(self.pg) if dist.is_available() and dist.is_initialized() else 1
+        self.arena = module.arena
+        if self.arena is None or self.arena.grad is None:
+            raise RuntimeError("wrap a finalized trainable model (module.finalize(device) first)")
+        self.works = []
+        self.launched = set()
+        self.comm_stream = None
+        self.tracker = None
+        if self.world > 1:
+            # (i) ctor broadcast of all params from rank 0 (TRAIN:87); buffers on this path are constants
+            dist.broadcast(self.arena.flat32, src=0, group=self.pg)
+            self.arena.refresh_shadow()
+            self.tracker = GradTracker(self.arena, bucket_bytes)
+            self.bucket_end = dict(self.tracker.buckets)
+            if overlap:
+                self.tracker.on_ready = self._launch_bucket
+                TRACKER = self.tracker
+            if self.arena.grad.is_cuda:
+                self.comm_stream = torch.cuda.Stream()
+
+    def forward(self, *a, **kw):
+        return self.module(*a, **kw)
+
+    def _launch_bucket(self, start):
+        if start in self.launched:
+            return
+        self.launched.add(start)
+        g = self.arena.grad[start:self.bucket_end[start]]
+        if self.comm_stream is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ev)
+                self.works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        else:
+            self.works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def reduce_gradients(self):
+        """Finish the step's gradient all-reduce: launch whatever backward did not already launch, then make the
+        compute stream wait for every bucket.  Gradients hold the SUM over ranks afterwards (AdamW divides)."""
+        if self.world == 1:
+            return
+        for start, _ in self.tracker.buckets:
+            self._launch_bucket(start)
+        for w in self.works:
+            w.wait()
+        self.works.clear()
+        self.launched.clear()
+        self.tracker.reset()

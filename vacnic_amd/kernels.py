@@ -254,6 +254,14 @@ def cat_tokens(parts):
     return out
 
 
+def pad_cols(x2d, Cp):
+    """[R, C] -> [R, Cp] zero padded (C not a multiple of 8)."""
+    R, C = x2d.shape
+    out = torch.empty((R, Cp), device=x2d.device, dtype=BF16)
+    call("vacnic_pad_cols_bf16", _p(x2d), _p(out), R, C, Cp, x2d.stride(0), _stream())
+    return out
+
+
 def add(a, b):
     out = torch.empty_like(a)
     assert a.is_contiguous() and b.is_contiguous()

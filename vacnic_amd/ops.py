@@ -1,0 +1,430 @@
+"""Autograd operators of the VACNIC path: torch.autograd.Function shells whose forward AND backward
+are hand-written HIP kernels called through the C-ABI (vacnic_amd.kernels).  torch.autograd only
+records the graph; no arithmetic runs in ATen.
+
+Conventions
+  * activations are bf16, contiguous; statistics / losses fp32.
+  * trainable weights live in a flat arena (vacnic_amd.arena): fp32 master + bf16 shadow + fp32
+    gradient.  Weight gradients are ACCUMULATED IN PLACE into the arena by the wgrad kernels
+    (split-K f32 atomics), so backward() returns None for parameters; the fp32 Parameter is still
+    passed to apply() as an "anchor" so autograd tracks the op even when the data input is not
+    differentiable.
+  * a tensor consumed by two ops goes through fork() so the gradient fan-in is our add kernel.
+"""
+import torch
+from torch.autograd import Function
+
+from . import ddp
+from . import kernels as K
+
+BF16 = torch.bfloat16
+
+
+class Rng:
+    """Dropout seeds: one fresh 64-bit seed per dropout site per step (Philox key); the kernels
+    regenerate masks from (seed, element index) in backward, nothing is stored."""
+    base = 0x5EED
+    counter = 0
+
+    @classmethod
+    def manual_seed(cls, s):
+        cls.base = int(s) & 0xFFFFFFFF
+        cls.counter = 0
+
+    @classmethod
+    def next(cls):
+        cls.counter += 1
+        return (cls.base << 32) | (cls.counter & 0xFFFFFFFF)
+
+
+class LinearSpec:
+    """What a GEMM needs to know about an nn.Linear: bf16 shadow weight [N,K], fp32 bias, grad views."""
+    __slots__ = ("w16", "bias", "wgrad", "bgrad", "N", "K", "ldw")
+
+    def __init__(self, w16, bias=None, wgrad=None, bgrad=None):
+        self.w16, self.bias, self.wgrad, self.bgrad = w16, bias, wgrad, bgrad
+        self.N, self.K = w16.shape
+        self.ldw = w16.stride(0)
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _wgrad(dy2d, x2d, spec, M):
+    """spec.wgrad[N,K] += dy^T x ; spec.bgrad[N] += colsum(dy)."""
+    _wgrad_impl(dy2d, x2d, spec, M)
+    ddp.done(spec.wgrad, spec.bgrad)
+
+
+def _wgrad_impl(dy2d, x2d, spec, M):
+    if spec.wgrad is not None:
+        N, Kd = spec.N, spec.K
+        tiles = ((N + 127) // 128) * ((Kd + 127) // 128)
+        K.gemm(dy2d, x2d, N, Kd, M, out=spec.wgrad, ldx=dy2d.stride(0), ldw=x2d.stride(0), ldo=spec.wgrad.stride(0),
+               x_kstrided=True, w_kstrided=True, out_mode=2, split_k=K.wgrad_split(M, tiles))
+    if spec.bgrad is not None:
+        K.bias_grad(dy2d, spec.bgrad, M, spec.N)
+
+
+# ------------------------------------------------------------------------------------------- Linear
+class LinearFn(Function):
+    """y = x W^T + b (+ residual).  nn.Linear on the path: q/kv/out projections, visual_map, _linear_1."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, spec, residual, ge):
+        Kd = spec.K
+        x2 = _c(x).view(-1, Kd)
+        M = x2.shape[0]
+        out = torch.empty(x.shape[:-1] + (spec.N,), device=x.device, dtype=BF16)
+        K.gemm(x2, spec.w16, M, spec.N, Kd, bias=spec.bias, out=out, ldw=spec.ldw,
+               residual=_c(residual) if residual is not None else None)
+        ctx.spec, ctx.M = spec, M
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(x2)
+        ddp.expect(ge and any(ctx.needs_input_grad), spec.wgrad, spec.bgrad)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2,) = ctx.saved_tensors
+        spec, M = ctx.spec, ctx.M
+        dy2 = _c(dy).view(M, spec.N)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, spec.K), device=dy.device, dtype=BF16)
+            K.gemm(dy2, spec.w16, M, spec.K, spec.N, out=dx, ldw=spec.ldw, w_kstrided=True)
+            dx = dx.view(dy.shape[:-1] + (spec.K,))
+        _wgrad(dy2, x2, spec, M)
+        return dx, None, None, (dy if ctx.has_res else None), None
+
+
+def linear(x, anchor, spec, residual=None):
+    return LinearFn.apply(x, anchor, spec, residual, torch.is_grad_enabled())
+
+
+# --------------------------------------------------------------------------------------------- MLP2
+class Mlp2Fn(Function):
+    """y = W2 act(W1 x + b1) + b2 — every two-layer block on the path: text/img/face FFN (MFULL:647-664,
+    738-741), name-prefix FFN on the flat view (:682-687), ClipCap prompt MLP (MFULL:111-123), ViT MLP.
+    The activation backward is fused into the dgrad GEMM epilogue (dact_src)."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, s1, s2, act, ge):
+        x2 = _c(x).view(-1, s1.K)
+        M = x2.shape[0]
+        need = ge and any(ctx.needs_input_grad)      # grad mode is always off inside Function.forward: `ge` comes from the caller
+        u = torch.empty((M, s1.N), device=x.device, dtype=BF16) if need else None
+        h = torch.empty((M, s1.N), device=x.device, dtype=BF16)
+        K.gemm(x2, s1.w16, M, s1.N, s1.K, bias=s1.bias, out=h, ldw=s1.ldw, act=act, preact=u)
+        out = torch.empty(x.shape[:-1] + (s2.N,), device=x.device, dtype=BF16)
+        K.gemm(h, s2.w16, M, s2.N, s2.K, bias=s2.bias, out=out, ldw=s2.ldw)
+        ctx.s1, ctx.s2, ctx.act, ctx.M = s1, s2, act, M
+        ctx.save_for_backward(x2, u, h)
+        ddp.expect(need, s1.wgrad, s1.bgrad, s2.wgrad, s2.bgrad)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, u, h = ctx.saved_tensors
+        s1, s2, act, M = ctx.s1, ctx.s2, ctx.act, ctx.M
+        dy2 = _c(dy).view(M, s2.N)
+        if s2.N % 8:                                   # 20-wide name-prefix output: give the GEMMs 16-byte rows
+            dy2 = K.pad_cols(dy2, (s2.N + 7) // 8 * 8)
+        du = torch.empty((M, s1.N), device=dy.device, dtype=BF16)
+        K.gemm(dy2, s2.w16, M, s1.N, s2.N, out=du, ldx=dy2.stride(0), ldw=s2.ldw, w_kstrided=True, act=act, dact_src=u)
+        _wgrad(dy2, h, s2, M)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, s1.K), device=dy.device, dtype=BF16)
+            K.gemm(du, s1.w16, M, s1.K, s1.N, out=dx, ldw=s1.ldw, w_kstrided=True)
+            dx = dx.view(dy.shape[:-1] + (s1.K,))
+        _wgrad(du, x2, s1, M)
+        return dx, None, None, None, None, None
+
+
+def mlp2(x, anchor, s1, s2, act="gelu"):
+    return Mlp2Fn.apply(x, anchor, s1, s2, act, torch.is_grad_enabled())
+
+
+# ---------------------------------------------------------------------------------------- attention
+class SelfAttnFn(Function):
+    """kvq: [B,T,3d] fused projection output, column blocks [K | V | Q] (arena order k,v,q)."""
+
+    @staticmethod
+    def forward(ctx, kvq, key_mask, causal, H, ge):
+        B, T, d3 = kvq.shape
+        d = d3 // 3
+        out, lse = K.attn_fwd(kvq[..., 2 * d:], kvq[..., :d], kvq[..., d:2 * d], B, H, T, T, key_mask=key_mask,
+                              causal=causal, scale=0.125, need_lse=ge and any(ctx.needs_input_grad))
+        ctx.cfg = (B, H, T, d, causal)
+        ctx.key_mask = key_mask
+        ctx.save_for_backward(kvq, out, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        kvq, out, lse = ctx.saved_tensors
+        B, H, T, d, causal = ctx.cfg
+        dkvq = torch.empty_like(kvq)
+        K.attn_bwd(kvq[..., 2 * d:], kvq[..., :d], kvq[..., d:2 * d], out, _c(dout), lse, dkvq[..., 2 * d:], dkvq[..., :d],
+                   dkvq[..., d:2 * d], B, H, T, T, key_mask=ctx.key_mask, causal=causal, scale=0.125)
+        return dkvq, None, None, None, None
+
+
+class CrossAttnFn(Function):
+    """q: [B,Tq,d]; kv: [B,Tk,2d] = [K | V]."""
+
+    @staticmethod
+    def forward(ctx, q, kv, key_mask, H, ge):
+        B, Tq, d = q.shape
+        Tk = kv.shape[1]
+        out, lse = K.attn_fwd(q, kv[..., :d], kv[..., d:], B, H, Tq, Tk, key_mask=key_mask, causal=False, scale=0.125,
+                              need_lse=ge and any(ctx.needs_input_grad))
+        ctx.cfg = (B, H, Tq, Tk, d)
+        ctx.key_mask = key_mask
+        ctx.save_for_backward(q, kv, out, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, kv, out, lse = ctx.saved_tensors
+        B, H, Tq, Tk, d = ctx.cfg
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(kv)
+        K.attn_bwd(q, kv[..., :d], kv[..., d:], out, _c(dout), lse, dq, dkv[..., :d], dkv[..., d:], B, H, Tq, Tk,
+                   key_mask=ctx.key_mask, causal=False, scale=0.125)
+        return dq, dkv, None, None, None
+
+
+def self_attention(kvq, key_mask, causal, H):
+    return SelfAttnFn.apply(kvq, key_mask, causal, H, torch.is_grad_enabled())
+
+
+def cross_attention(q, kv, key_mask, H):
+    return CrossAttnFn.apply(q, kv, key_mask, H, torch.is_grad_enabled())
+
+
+# -------------------------------------------------------------------------------------------- LN family
+class AddLnFn(Function):
+    """LayerNorm(residual + dropout(x)); residual may be None (plain LN)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, gamma, beta, p_drop, seed, ge):
+        x = _c(x)
+        res = _c(residual) if residual is not None else None
+        need = ge and any(ctx.needs_input_grad)
+        out, mean, rstd = K.add_ln_fwd(x, res, gamma, beta, p_drop=p_drop, seed=seed, need_stats=need)
+        ctx.p, ctx.seed = p_drop, seed
+        ctx.gb = (gamma, beta)
+        ctx.has_res = res is not None
+        ctx.save_for_backward(x, res, mean, rstd)
+        ddp.expect(need, gamma.grad, beta.grad)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, res, mean, rstd = ctx.saved_tensors
+        gamma, beta = ctx.gb
+        dx, dres = K.add_ln_bwd(_c(dout), x, res, gamma, mean, rstd, gamma.grad, beta.grad, p_drop=ctx.p, seed=ctx.seed,
+                                need_dres=ctx.has_res and ctx.needs_input_grad[1])
+        ddp.done(gamma.grad, beta.grad)
+        return (dx if ctx.needs_input_grad[0] else None), (dres if ctx.has_res and ctx.needs_input_grad[1] else None), None, None, None, None, None
+
+
+def add_ln(x, residual, gamma, beta, p_drop=0.0, training=False):
+    p = p_drop if training else 0.0
+    return AddLnFn.apply(x, residual, gamma, beta, p, Rng.next() if p > 0 else 0, torch.is_grad_enabled())
+
+
+class EmbedLnFn(Function):
+    """dropout(LayerNorm(embed[ids]*scale + pos[t+2])) (MFULL:1243-1249)."""
+
+    @staticmethod
+    def forward(ctx, ids, tok, pos, gamma, beta, scale, p_drop, seed, padding_idx, ge):
+        out, mean, rstd = K.embed_ln_fwd(ids, tok.w16, pos.w16, gamma, beta, embed_scale=scale, p_drop=p_drop, seed=seed)
+        ctx.args = (tok, pos, gamma, beta, scale, p_drop, seed, padding_idx)
+        ctx.save_for_backward(ids, mean, rstd)
+        ddp.expect(ge and any(ctx.needs_input_grad), tok.grad, pos.grad, gamma.grad, beta.grad)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ids, mean, rstd = ctx.saved_tensors
+        tok, pos, gamma, beta, scale, p, seed, pad = ctx.args
+        K.embed_ln_bwd(ids, tok.w16, pos.w16, _c(dout), gamma, mean, rstd, tok.grad, pos.grad, gamma.grad, beta.grad,
+                       embed_scale=scale, padding_idx=pad, p_drop=p, seed=seed)
+        ddp.done(tok.grad, pos.grad, gamma.grad, beta.grad)
+        return (None,) * 10
+
+
+def embed_ln(ids, tok, pos, gamma, beta, scale=1.0, p_drop=0.0, training=False, padding_idx=1):
+    p = p_drop if training else 0.0
+    return EmbedLnFn.apply(ids, tok, pos, gamma, beta, scale, p, Rng.next() if p > 0 else 0, padding_idx, torch.is_grad_enabled())
+
+
+# -------------------------------------------------------------------------------------------- plumbing
+class ForkFn(Function):
+    """identity with two consumers; backward = our bf16 add of the two incoming gradients."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        if g1 is None:
+            return g2
+        if g2 is None:
+            return g1
+        return K.add(_c(g1), _c(g2))
+
+
+def fork(x):
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return x, x
+    return ForkFn.apply(x)
+
+
+class CatTokensFn(Function):
+    """torch.cat(parts, dim=1) (MFULL:668,691) as strided copies; backward slices by strided copies."""
+
+    @staticmethod
+    def forward(ctx, *parts):
+        ctx.lens = [p.shape[1] for p in parts]
+        return K.cat_tokens([_c(p) for p in parts])
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        B, _, D = g.shape
+        outs, o = [], 0
+        for i, n in enumerate(ctx.lens):
+            if ctx.needs_input_grad[i]:
+                t = torch.empty((B, n, D), device=g.device, dtype=BF16)
+                K.copy3d(g[:, o:o + n], t, B, n, D)
+                outs.append(t)
+            else:
+                outs.append(None)
+            o += n
+        return tuple(outs)
+
+
+def cat_tokens(*parts):
+    return CatTokensFn.apply(*parts)
+
+
+class CastInFn(Function):
+    """fp32 input -> bf16 activation (no gradient: inputs are data)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return K.cast_f32_bf16(_c(x))
+
+    @staticmethod
+    def backward(ctx, g):
+        return None
+
+
+def to_bf16(x):
+    return x if x.dtype == BF16 else CastInFn.apply(x)
+
+
+# ---------------------------------------------------------------------------------------------- losses
+class LmHeadCeFn(Function):
+    """lm_head (tied to shared, MFULL:1885,1997) + CrossEntropyLoss(ignore_index=pad) (TRAIN:287).
+    Logits are materialised once in fp32 [R, V_pad]; backward overwrites a bf16 buffer with dlogits and
+    runs the two GEMMs (dh, dE)."""
+
+    @staticmethod
+    def forward(ctx, h, anchor, emb16_pad, egrad, targets, V, ignore_index, ge):
+        d = h.shape[-1]
+        h2 = _c(h).view(-1, d)
+        R = h2.shape[0]
+        Vp = emb16_pad.shape[0]
+        logits = torch.empty((R, Vp), device=h.device, dtype=torch.float32)
+        K.gemm(h2, emb16_pad, R, V, d, out=logits, ldo=Vp, out_mode=1)
+        tgt = _c(targets).view(-1)
+        row_lse, acc = K.ce_fwd(logits, tgt, V, ignore_index=ignore_index)
+        out4 = K.combine_losses(acc.data_ptr(), acc.data_ptr() + 4, None, None, 0.0, 0.0, h.device)
+        ctx.misc = (emb16_pad, egrad, V, ignore_index, R, d, h.shape)
+        ctx.save_for_backward(h2, logits, tgt, row_lse, acc)
+        ctx.mark_non_differentiable(acc)
+        ddp.expect(ge and any(ctx.needs_input_grad), egrad)
+        return out4[1], acc
+
+    @staticmethod
+    def backward(ctx, g, _gacc):
+        h2, logits, tgt, row_lse, acc = ctx.saved_tensors
+        emb16_pad, egrad, V, ignore_index, R, d, hshape = ctx.misc
+        Vp = emb16_pad.shape[0]
+        dl = torch.empty((R, Vp), device=h2.device, dtype=BF16)
+        K.ce_bwd(logits, tgt, V, row_lse, acc, dl, grad_out=_c(g), grad_scale=1.0, ignore_index=ignore_index)
+        dh = torch.empty((R, d), device=h2.device, dtype=BF16)
+        K.gemm(dl, emb16_pad, R, d, Vp, out=dh, w_kstrided=True)          # dh = dlogits . E   (pad rows of E are zero)
+        if egrad is not None:                                               # dE[V,d] += dlogits^T h
+            tiles = ((V + 127) // 128) * ((d + 127) // 128)
+            K.gemm(dl, h2, V, d, R, out=egrad, ldx=Vp, ldw=d, ldo=d, x_kstrided=True, w_kstrided=True, out_mode=2,
+                   split_k=K.wgrad_split(R, tiles))
+        ddp.done(egrad)
+        return dh.view(hshape), None, None, None, None, None, None, None
+
+
+def lm_head_ce(h, anchor, emb16_pad, egrad, targets, V, ignore_index=1):
+    loss, acc = LmHeadCeFn.apply(h, anchor, emb16_pad, egrad, targets, V, ignore_index, torch.is_grad_enabled())
+    return loss, acc
+
+
+class ColamFn(Function):
+    """weight * CoLaM margin loss (TRAIN:296-307,820); gradient flows only into the student states."""
+
+    @staticmethod
+    def forward(ctx, hs, hg, mask_u8, margin, weight):
+        loss, cos, ps, pg = K.colam_fwd(_c(hs), _c(hg), mask_u8, margin)
+        ctx.misc = (mask_u8, tuple(hs.shape), margin, weight)
+        ctx.save_for_backward(cos, ps, pg)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        cos, ps, pg = ctx.saved_tensors
+        mask_u8, shape, margin, weight = ctx.misc
+        return K.colam_bwd(cos, ps, pg, mask_u8, shape, margin, _c(g), weight), None, None, None, None
+
+
+class SeclaFn(Function):
+    """SECLA BatchSoftmax(face, names) (TRAIN:631-660); names carry no gradient (TRAIN:117 no_grad)."""
+
+    @staticmethod
+    def forward(ctx, faces, names, weight):
+        faces = _c(faces)
+        loss, sim, l1, l2 = K.secla_fwd(faces, names)
+        ctx.weight = weight
+        ctx.save_for_backward(faces, names, sim, l1, l2)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        faces, names, sim, l1, l2 = ctx.saved_tensors
+        return K.secla_bwd(faces, names, sim, l1, l2, _c(g), ctx.weight), None, None
+
+
+class TotalLossFn(Function):
+    """loss = txt + w_secla*secla + w_colam*colam (TRAIN:363).  The weights are applied here in the
+    forward value and handed to each loss's backward as grad_scale (ColamFn/SeclaFn `weight`)."""
+
+    @staticmethod
+    def forward(ctx, txt, secla, colam, w_secla, w_colam):
+        one = torch.ones((), device=txt.device, dtype=torch.float32)
+        out4 = K.combine_losses(txt.data_ptr(), one.data_ptr(), secla, colam, w_secla, w_colam, txt.device)
+        ctx.has = (secla is not None, colam is not None)
+        ctx.mark_non_differentiable(out4)
+        return out4[0], out4
+
+    @staticmethod
+    def backward(ctx, g, _g4):
+        return g, (g if ctx.has[0] else None), (g if ctx.has[1] else None), None, None
+
+
+def total_loss(txt, secla, colam, w_secla, w_colam):
+    return TotalLossFn.apply(txt, secla, colam, w_secla, w_colam)

@@ -1,0 +1,155 @@
+"""One VACNIC training step on gfx950 kernels — the body of train_epoch (TRAIN:253-383) without the
+host syncs: ViT features -> multimodal BART (+ fused lm_head/CE) -> frozen guide BART -> CoLaM ->
+SECLA -> backward -> DDP all-reduce -> fused AdamW with on-device linear-warmup schedule.
+"""
+from dataclasses import dataclass
+
+import torch
+
+from . import kernels as K
+from . import ops
+from .config import ClipVisionConfig, VacnicConfig
+from .ddp import DistributedDataParallel
+from .models.clip_vit import CLIPVisualOnly, extract_clip_img_feat
+from .models.guide_bart import BartForConditionalGeneration
+from .models.mmbart import BartForMultiModalGeneration
+
+
+@dataclass
+class TrainArgs:
+    """the trainer flags that shape the step (names/defaults of TRAIN:5-82, values of run_full_train.sh)."""
+    lr_bart: float = 3e-5
+    weight_decay: float = 0.01
+    warmup_rate: float = 0.05
+    num_training_steps: int = 100000
+    margin: float = 1.0
+    alpha: float = 0.5
+    mapping_loss_weight: float = 1.0
+    use_secla: bool = True
+    no_mapping: bool = False
+    no_clip_norm: bool = True
+    prompt_mlp_type: str = "clipcap"
+
+
+class FusedAdamW:
+    """optim.AdamW(betas=(0.9,0.999), eps=1e-8) + get_linear_schedule_with_warmup (TRAIN:91,99-107) over the
+    gradient arena: one lr kernel + one AdamW kernel per step, lr and step counter in device memory."""
+
+    def __init__(self, arena, lr, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8, num_warmup_steps=0.0,
+                 num_training_steps=1.0, world_size=1):
+        self.arena = arena
+        arena.init_optimizer_state()
+        self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
+        self.warmup, self.total = float(num_warmup_steps), float(num_training_steps)
+        self.world = world_size
+        self.hyper = torch.zeros(2, device=arena.device, dtype=torch.float32)      # {lr, step}
+
+    def step(self):
+        a = self.arena
+        K.lr_step(self.hyper, self.lr, self.warmup, self.total)
+        K.adamw(a.flat32, a.grad, a.exp_avg, a.exp_avg_sq, a.flat16, self.hyper, a.n, self.betas[0], self.betas[1],
+                self.eps, self.wd, grad_scale=1.0 / self.world, zero_grad=True)
+
+    def zero_grad(self):
+        pass            # fused into step(): the AdamW kernel clears the gradient arena it just consumed
+
+    def state_dict(self):
+        return {"exp_avg": self.arena.exp_avg, "exp_avg_sq": self.arena.exp_avg_sq, "hyper": self.hyper}
+
+
+def build_models(cfg: VacnicConfig, vcfg: ClipVisionConfig, device="cuda", seed=0, init="device", state_dicts=None):
+    """Random-init (or state-dict) construction of the three networks of the step, finalized in HBM arenas.
+    init='device': N(0, 0.02) drawn on the GPU (fast, for benchmarks); init='synthetic': name-keyed numpy
+    weights identical to the oracle's (parity tests)."""
+    from . import synthetic
+    clip_model = CLIPVisualOnly(vcfg)
+    model = BartForMultiModalGeneration(cfg, enc_fusion_layer=cfg.enc_fusion_layer, dim_common=cfg.dim_common, img_size=768,
+                                        prompt_mlp_type=cfg.prompt_mlp_type, prompt_size=cfg.prompt_size, clip_model=None,
+                                        freeze_clip=True, max_ner_type_len=cfg.max_ner_type_len,
+                                        max_ner_type_len_gt=cfg.max_ner_type_len_gt, only_image=cfg.only_image)
+    guide = BartForConditionalGeneration(cfg)
+    if init == "synthetic" or state_dicts is not None:
+        sds = state_dicts or (synthetic.make_state_dict(synthetic.mmbart_param_shapes(cfg), seed=seed + 1),
+                              synthetic.make_state_dict(synthetic.guide_bart_param_shapes(cfg), seed=seed + 2),
+                              synthetic.make_state_dict(synthetic.clip_visual_param_shapes(vcfg), seed=seed + 4, std=0.05))
+        load_named(model, sds[0]); load_named(guide, sds[1]); load_named(clip_model.visual, sds[2])
+    model.finalize(device)
+    guide.finalize(device)
+    clip_model.finalize(device)
+    if init == "device" and state_dicts is None:
+        g = torch.Generator(device=device).manual_seed(seed)
+        for m, std in ((model, cfg.init_std), (guide, cfg.init_std), (clip_model.visual, 0.02)):
+            for name, p in m.named_parameters():
+                if p.dim() >= 2 or "embedding" in name:
+                    p.data.normal_(0.0, std, generator=g)
+                elif name.endswith("weight"):
+                    p.data.fill_(1.0)
+                else:
+                    p.data.zero_()
+            m.arena.refresh_shadow()
+    model.clip_model = clip_model                     # the reference keeps CLIP inside the model (MFULL:1892; TRAIN:274)
+    return model, guide, clip_model
+
+
+def load_named(module, sd):
+    params = dict(module.named_parameters())
+    missing = [k for k in params if k not in sd and not k.endswith("embed_tokens.weight") and k != "lm_head.weight"]
+    if missing:
+        raise KeyError(f"state dict lacks {missing[:5]} ...")
+    with torch.no_grad():
+        for k, p in params.items():
+            if k in sd:
+                if tuple(sd[k].shape) != tuple(p.shape):
+                    raise ValueError(f"shape mismatch for {k}: {tuple(sd[k].shape)} vs {tuple(p.shape)}")
+                p.data.copy_(sd[k])
+
+
+def to_device(batch, device):
+    return {k: v.to(device, non_blocking=True) for k, v in batch.items()}
+
+
+def forward_losses(model, guide, batch, args: TrainArgs):
+    """Forward of one step; returns (total, out4={total, txt, secla*w?, colam}, model_out).  `model` may be the
+    DDP wrapper (like TRAIN:274 `model.module`)."""
+    net = model.module if isinstance(model, DistributedDataParallel) else model
+    cfg = net.config
+    src, tgt = batch["article_ids"], batch["caption_ids"]
+    src_mask, _ = K.prep_ids(src, cfg.pad_token_id)                                          # create_src_mask_bart, TRAIN:268
+    tgt_mask, tgt_in = K.prep_ids(tgt, cfg.pad_token_id, start_id=cfg.eos_token_id)         # shift_tokens_right, TRAIN:267,296
+    _, img_cls = extract_clip_img_feat(net.clip_model, batch["img_tensor"])                   # TRAIN:274-276
+    kw = {}
+    if not cfg.only_image:
+        names_mask, _ = K.prep_ids(batch["names_art_ids"], cfg.pad_token_id)                 # TRAIN:270
+        kw = dict(face_features=batch["face_emb"], face_mask=K.face_mask(batch["face_emb"]), name_ids=batch["names_art_ids"],
+                  name_mask=names_mask)
+    out = model(input_ids=src, attention_mask=src_mask, decoder_input_ids=tgt_in, image_features=img_cls, labels=tgt,
+                output_logits=False, add_ner_ffn=True, **kw)                                  # TRAIN:281 + fused CE (TRAIN:287)
+    txt = out["loss"]
+    colam = secla = None
+    if guide is not None:
+        gh = guide(input_ids=src, attention_mask=src_mask, decoder_input_ids=tgt_in)["decoder_hidden_states"][-1]   # TRAIN:293-294
+        colam = ops.ColamFn.apply(out["decoder_hidden_states"][-1], gh, tgt_mask, args.margin, args.alpha)        # TRAIN:296-307
+    if args.use_secla and not args.no_mapping and not cfg.only_image:
+        enc = net.model.encoder
+        ln = enc.layernorm_embedding_ner
+        names = K.name_embed_mean(batch["names_ids"], enc.embed_tokens_ner.weight.w16, enc.embed_positions_ner.weight.w16,
+                                  ln.weight.data, ln.bias.data, embed_scale=enc.embed_scale)   # get_embedding_ner, TRAIN:327
+        secla = ops.SeclaFn.apply(out["hidden_states_face"], names, args.mapping_loss_weight)  # TRAIN:329
+    total, out4 = ops.total_loss(txt, secla, colam, args.mapping_loss_weight, args.alpha)      # TRAIN:363
+    return total, out4, out
+
+
+def train_step(model, guide, optimizer, batch, args: TrainArgs):
+    """loss.backward(); optimizer.step(); scheduler.step(); zero_grad()  (TRAIN:364-374) — returns the device-side
+    loss vector {total, txt, secla, colam} WITHOUT syncing (the reference's four .item() calls per step are gone)."""
+    net = model.module if isinstance(model, DistributedDataParallel) else model
+    net.train()
+    total, out4, _ = forward_losses(model, guide, batch, args)
+    total.backward()
+    if isinstance(model, DistributedDataParallel):
+        model.reduce_gradients()
+    if not args.no_clip_norm:
+        raise NotImplementedError("clip_grad_norm_ (TRAIN:365-366): shipped scripts pass --no_clip_norm True")
+    optimizer.step()
+    optimizer.zero_grad()
+    return out4
