@@ -26,6 +26,14 @@ PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak, MI355X_MICROARCH.md
 STEP_GFLOP_PER_SAMPLE = {512: 1179.8, 1024: 2142.7}      # SURVEY §8d (3*F_t + F_g + F_v)
 
 
+T0 = time.time()
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench +{time.time() - T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -35,7 +43,7 @@ def parse():
     ap.add_argument("--seq", type=int, default=512, help="article tokens S")
     ap.add_argument("--cap", type=int, default=64, help="caption tokens T")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=1)
     return ap.parse_args()
 
 
@@ -82,12 +90,22 @@ def cpu_baseline(cfg, vcfg, B, S, T):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    cores = min(cores, 16)                      # the box's CPU share for one GPU; more threads only thrash
     torch.set_num_threads(cores)
-    g = torch.Generator().manual_seed(0)
+    pool = torch.randn(1 << 24, generator=torch.Generator().manual_seed(0)) * 0.02
 
     def rand_sd(shapes):
-        return {k: (torch.randn(v, generator=g) * 0.02 if len(v) > 1 else (torch.ones(v) if k.endswith("weight") else torch.zeros(v)))
-                for k, v in shapes.items()}
+        # timing only: weights are slices/tiles of one random pool (drawing 1.6 G normals would take a minute)
+        out = {}
+        for k, v in shapes.items():
+            n = 1
+            for d in v:
+                n *= d
+            if len(v) > 1:
+                out[k] = (pool[:n] if n <= pool.numel() else pool.repeat((n + pool.numel() - 1) // pool.numel())[:n]).clone().view(v)
+            else:
+                out[k] = torch.ones(v) if k.endswith("weight") else torch.zeros(v)
+        return out
     sd = rand_sd(synthetic.mmbart_param_shapes(cfg))
     sd_g = rand_sd(synthetic.guide_bart_param_shapes(cfg))
     sd_c = rand_sd(synthetic.clip_visual_param_shapes(vcfg))
@@ -106,12 +124,15 @@ def cpu_baseline(cfg, vcfg, B, S, T):
                     continue
                 np_, m[k], vv[k] = O.adamw_step(p, p.grad, m[k], vv[k], i + 1, 3e-5)
                 p.copy_(np_); p.grad = None
+    log("  oracle weights ready; warm-up step")
     step(0)                                     # warm-up
     best = 1e30
-    for i in range(2):
+    for i in range(1):
         t0 = time.time(); step(i + 1); best = min(best, time.time() - t0)
+        log(f"  oracle step {i}: {time.time() - t0:.1f}s")
     return {"value": round(B / best, 4), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (torch fp32 CPU) full train step, same model/shapes, batch {B} (S={S}, T={T}), best of 2 after 1 warm-up"}
+            "sample": f"oracle (torch fp32 CPU, {cores} threads) full train step fwd+bwd+AdamW, same model/shapes, batch {B} "
+                      f"(S={S}, T={T}), 1 timed step after 1 warm-up"}
 
 
 def main():
@@ -132,7 +153,9 @@ def main():
 
     cfg, vcfg = bart_large_vit_l14()
     B, S, T = a.batch, a.seq, a.cap
+    log("building models (random init on device)")
     model, guide, _ = build_models(cfg, vcfg, device="cuda", seed=1234, init="device")
+    log(f"models ready: {model.arena.n/1e6:.1f}M trainable, {guide.arena.n/1e6:.1f}M guide, {model.clip_model.visual.arena.n/1e6:.1f}M ViT")
     args = TrainArgs(num_training_steps=100000)
     net = DistributedDataParallel(model) if world > 1 else model
     opt = FusedAdamW(model.arena, lr=args.lr_bart, weight_decay=args.weight_decay,
@@ -142,9 +165,11 @@ def main():
     batches = [to_device(synthetic.make_batch(cfg, B, S=S, T=T, seed=42, rank=rank, step=i, full_length=True), "cuda") for i in range(nb)]
     torch.cuda.synchronize()
 
+    log("batches resident; warm-up")
     for i in range(a.warmup):
         train_step(net, guide, opt, batches[i % nb], args)
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        log(f"warm-up step {i} done")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -166,6 +191,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     losses = out4.tolist()
+    log(f"timed {a.steps} steps in {dt:.3f}s; losses {losses}")
     if rank == 0:
         agg = timer.summary()
         dom = max(agg.items(), key=lambda kv: kv[1][1]) if agg else None
@@ -195,7 +221,9 @@ def main():
                "roofline": roof}
         if world == 1 and not a.no_cpu_baseline:
             try:
+                log("cpu baseline (oracle on host cores)")
                 res["cpu_baseline"] = cpu_baseline(cfg, vcfg, a.cpu_batch, S, T)
+                log("cpu baseline done")
             except Exception as e:      # the baseline must never sink the GPU measurement
                 res["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
         print(json.dumps(res))

