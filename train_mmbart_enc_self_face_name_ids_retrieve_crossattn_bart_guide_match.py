@@ -1,0 +1,142 @@
+"""Entry point with the reference trainer's file name and flags (TRAIN:5-82) for the MI355X-native VACNIC step.
+
+    torchrun --nproc_per_node=N train_mmbart_enc_self_face_name_ids_retrieve_crossattn_bart_guide_match.py \
+        --plm_type facebook/bart-large --clip_type ViT-L/14 --enc_fusion_layer 0 1 ... 11 --dim_common 1024 \
+        --train_batch_size 32 --prompt_size 20 --use_secla True --margin 1.0 --alpha 0.5 --no_clip_norm True ...
+
+Scope: the data-parallel training hot path.  Datasets, tokenizers, pretrained checkpoints, wandb and
+caption scoring are out of scope and there is no network here, so `--data_type synthetic` (default) feeds
+GoodNews-shaped synthetic batches and weights are random-initialised; a user with the real datasets
+plugs a DataLoader that yields the same batch dict (DSG:22-127) into `run()`.
+One process per GPU: rank/world come from torchrun's env (TRAIN:616-620 uses LOCAL_RANK the same way).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+_b = lambda x: (str(x).lower() == "true")    # noqa: E731  (TRAIN's boolean flag idiom)
+parser = argparse.ArgumentParser()
+parser.add_argument("--seed", type=str, default="684331")
+parser.add_argument("--gpu_ids", type=str, default="0")
+parser.add_argument("--num_workers", type=int, default=4)
+parser.add_argument("--article_max_length", type=int, default=512)
+parser.add_argument("--caption_max_length", type=int, default=100)
+parser.add_argument("--plm_type", type=str, default="facebook/bart-large")
+parser.add_argument("--clip_type", type=str, default="ViT-L/14")
+parser.add_argument("--ent_start_token", type=str, default="no")
+parser.add_argument("--ent_end_token", type=str, default="no")
+parser.add_argument("--enc_fusion_layer", nargs="+", type=int)
+parser.add_argument("--dim_common", type=int, default=1024)
+parser.add_argument("--warmup_rate", type=float, default=0.05)
+parser.add_argument("--train_batch_size", type=int, default=32)
+parser.add_argument("--val_batch_size", type=int, default=1)
+parser.add_argument("--test_batch_size", type=int, default=1)
+parser.add_argument("--beam_size", type=int, default=1)
+parser.add_argument("--max_length", type=int, default=50)
+parser.add_argument("--num_epoch", type=int, default=1)
+parser.add_argument("--lr_bart", type=float, default=3e-5)
+parser.add_argument("--lr_clip", type=float, default=5e-6)
+parser.add_argument("--weight_decay", type=float, default=0.01)
+parser.add_argument("--clip_norm", type=float, default=0.1)
+parser.add_argument("--data_type", type=str, default="synthetic")
+parser.add_argument("--data_dir", type=str, default=".")
+parser.add_argument("--out_dir", type=str, default=".")
+parser.add_argument("--mapping_loss_type", type=str, default="contrastive")
+parser.add_argument("--trained_clip", type=str, default="no")
+parser.add_argument("--clip_dir", type=str, default=".")
+parser.add_argument("--no_clip_loss", default=True, type=_b)
+parser.add_argument("--prompt_size", type=int, default=20)
+parser.add_argument("--use_vis_cls", default=True, type=_b)
+parser.add_argument("--max_ner_type_len", type=int, default=80)
+parser.add_argument("--max_ner_type_len_gt", type=int, default=20)
+parser.add_argument("--freeze_clip", default=True, type=_b)
+parser.add_argument("--prompt_mlp_type", type=str, default="clipcap")
+parser.add_argument("--map_size", nargs="+", type=int)
+parser.add_argument("--no_mapping", default=False, type=_b)
+parser.add_argument("--mapping_loss_weight", type=float, default=1.0)
+parser.add_argument("--img_size", type=int, default=768)
+parser.add_argument("--only_image", default=False, type=_b)
+parser.add_argument("--use_secla", default=True, type=_b)
+parser.add_argument("--num_sentences", type=int, default=8)
+parser.add_argument("--adapter_dim", type=int, default=96)
+parser.add_argument("--project_name", type=str, default="news_cap")
+parser.add_argument("--experiment_name", type=str, default="vacnic_mi355x")
+parser.add_argument("--offline_wandb", default=True, type=_b)
+parser.add_argument("--perturb", default=False, type=_b)
+parser.add_argument("--no_clip_norm", default=True, type=_b)
+parser.add_argument("--init_attn_weight", default=False, type=_b)
+parser.add_argument("--margin", type=float, default=1.0)
+parser.add_argument("--alpha", type=float, default=0.5)
+# additions for the synthetic driver
+parser.add_argument("--steps_per_epoch", type=int, default=20)
+parser.add_argument("--log_every", type=int, default=5)
+
+PLM = {"facebook/bart-base": dict(d_model=768, encoder_layers=6, decoder_layers=6, encoder_attention_heads=12,
+                                  decoder_attention_heads=12, encoder_ffn_dim=3072, decoder_ffn_dim=3072),
+       "facebook/bart-large": dict(), "patrickvonplaten/bart-large-fp32": dict()}
+CLIP = {"ViT-B/32": dict(width=768, layers=12, patch_size=32, output_dim=512), "ViT-B/16": dict(width=768, layers=12, patch_size=16, output_dim=512),
+        "ViT-L/14": dict(width=1024, layers=24, patch_size=14, output_dim=768)}
+
+
+def run(args, batches=None):
+    import torch
+    import torch.distributed as dist
+    from vacnic_amd import ops, synthetic
+    from vacnic_amd.config import ClipVisionConfig, VacnicConfig
+    from vacnic_amd.ddp import DistributedDataParallel
+    from vacnic_amd.training import FusedAdamW, TrainArgs, build_models, to_device, train_step
+
+    if not args.no_clip_loss or not args.freeze_clip:
+        raise NotImplementedError("CLIP contrastive loss / CLIP fine-tuning are out of scope (SURVEY §2 row 20): pass --no_clip_loss True --freeze_clip True")
+    if not args.no_mapping and not args.use_secla and not args.only_image:
+        raise NotImplementedError("non-SECLA face-name branch (TRAIN:332-355) is out of scope (SURVEY §2 row 21): pass --use_secla True")
+    local = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    ops.Rng.manual_seed(int(args.seed) + rank)
+    vkw = CLIP[args.clip_type]
+    cfg = VacnicConfig(enc_fusion_layer=list(args.enc_fusion_layer or []), dim_common=args.dim_common, prompt_size=args.prompt_size,
+                       max_ner_type_len=args.max_ner_type_len, max_ner_type_len_gt=args.max_ner_type_len_gt,
+                       only_image=args.only_image, clip_width=vkw["width"], prompt_mlp_type=args.prompt_mlp_type,
+                       **PLM[args.plm_type]).validate()
+    vcfg = ClipVisionConfig(**vkw)
+    model, guide, _ = build_models(cfg, vcfg, device="cuda", seed=int(args.seed) % (2 ** 31), init="device")
+    total_steps = args.num_epoch * args.steps_per_epoch          # TRAIN:99 (not divided by world size there either)
+    targs = TrainArgs(lr_bart=args.lr_bart, weight_decay=args.weight_decay, warmup_rate=args.warmup_rate,
+                      num_training_steps=total_steps, margin=args.margin, alpha=args.alpha,
+                      mapping_loss_weight=args.mapping_loss_weight, use_secla=args.use_secla, no_mapping=args.no_mapping,
+                      no_clip_norm=args.no_clip_norm)
+    net = DistributedDataParallel(model, device_ids=[local], output_device=local) if world > 1 else model
+    opt = FusedAdamW(model.arena, lr=args.lr_bart, weight_decay=args.weight_decay, num_warmup_steps=args.warmup_rate * total_steps,
+                     num_training_steps=total_steps, world_size=world)
+    step, t0, hist = 0, time.time(), []
+    for epoch in range(int(args.num_epoch)):
+        it = batches if batches is not None else (
+            synthetic.make_batch(cfg, args.train_batch_size, S=args.article_max_length, T=min(64, args.caption_max_length), seed=int(args.seed) % 65536,
+                                 rank=rank, step=epoch * args.steps_per_epoch + i) for i in range(args.steps_per_epoch))
+        for batch in it:
+            out4 = train_step(net, guide if not args.only_image else None, opt, to_device(batch, "cuda"), targs)
+            step += 1
+            if step % args.log_every == 0 and rank == 0:          # ONE device->host sync per log interval (the reference does 4 per step)
+                tot, txt, secla, colam = out4.tolist()
+                rec = {"step": step, "loss": tot, "text loss": txt, "face name loss": secla, "margin loss": colam,
+                       "samples_per_s": round(step * args.train_batch_size * world / (time.time() - t0), 2)}
+                hist.append(rec)
+                print(json.dumps(rec), flush=True)
+    torch.cuda.synchronize()
+    if rank == 0 and args.out_dir:
+        os.makedirs(args.out_dir, exist_ok=True)
+        torch.save({k: v.detach().float().cpu() for k, v in model.state_dict().items() if not k.startswith("clip_model")},
+                   os.path.join(args.out_dir, args.experiment_name + "last.pt"))        # state_dict with MFULL names (TRAIN:472 pickles the module)
+    if world > 1:
+        dist.destroy_process_group()
+    return hist
+
+
+if __name__ == "__main__":
+    run(parser.parse_args())
