@@ -83,81 +83,77 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int rbase, int
   }
 }
 
-__device__ __forceinline__ void store_quad(const GemmP& p, f32x4 c, int m, int n, bool add_bias) {
+// Epilogue on 8 consecutive outputs of one row (read back from the LDS-staged C tile): bias, saved
+// pre-activation, activation or fused activation-backward, residual, then a 16-byte (bf16) /
+// 2x16-byte (f32) store or 8 f32 atomics on 32 contiguous bytes.
+__device__ __forceinline__ void load8bf(const bf16_t* p, float v[8]) {
+  u32x4 r = *(const u32x4*)p;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(r[i] << 16); v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u); }
+}
+__device__ __forceinline__ void store8bf(bf16_t* p, const float v[8]) {
+  *(u32x4*)p = (u32x4){pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+}
+
+__device__ __forceinline__ void epilogue8(const GemmP& p, float v[8], int m, int n, bool add_bias, bool vec_ok) {
   const size_t off = (size_t)m * p.ldo + n;
-  const int nv = p.N - n;               // >= 1; 4 or more means the whole quad is in range
-  float v0 = c[0] * p.alpha, v1 = c[1] * p.alpha, v2 = c[2] * p.alpha, v3 = c[3] * p.alpha;
+  const int nv = min(8, p.N - n);
+  const bool vec = vec_ok && nv == 8;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] *= p.alpha;
   if (p.bias && add_bias) {
-    v0 += p.bias[n];
-    if (nv > 1) v1 += p.bias[n + 1];
-    if (nv > 2) v2 += p.bias[n + 2];
-    if (nv > 3) v3 += p.bias[n + 3];
-  }
-  const bool vec = (nv >= 4) && ((p.ldo & 3) == 0);
-  if (p.preact) {
-    if (vec) {
-      *(u32x2*)(p.preact + off) = (u32x2){pack2bf(v0, v1), pack2bf(v2, v3)};
+    if (nv == 8) {
+      const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);   // arena slots are 16-byte aligned, n % 8 == 0
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[j] += b0[j]; v[4 + j] += b1[j]; }
     } else {
-      p.preact[off] = f2bf(v0);
-      if (nv > 1) p.preact[off + 1] = f2bf(v1);
-      if (nv > 2) p.preact[off + 2] = f2bf(v2);
-      if (nv > 3) p.preact[off + 3] = f2bf(v3);
+      for (int j = 0; j < nv; ++j) v[j] += p.bias[n + j];
     }
+  }
+  if (p.preact) {
+    if (vec) store8bf(p.preact + off, v);
+    else for (int j = 0; j < nv; ++j) p.preact[off + j] = f2bf(v[j]);
   }
   if (p.dact_src) {
-    float d0, d1 = 0.f, d2 = 0.f, d3 = 0.f;
-    if (vec) {
-      u32x2 d = *(const u32x2*)(p.dact_src + off);
-      d0 = __uint_as_float(d[0] << 16); d1 = __uint_as_float(d[0] & 0xffff0000u);
-      d2 = __uint_as_float(d[1] << 16); d3 = __uint_as_float(d[1] & 0xffff0000u);
-    } else {
-      d0 = bf2f(p.dact_src[off]);
-      if (nv > 1) d1 = bf2f(p.dact_src[off + 1]);
-      if (nv > 2) d2 = bf2f(p.dact_src[off + 2]);
-      if (nv > 3) d3 = bf2f(p.dact_src[off + 3]);
-    }
-    v0 *= act_bwd(p.act, d0); v1 *= act_bwd(p.act, d1); v2 *= act_bwd(p.act, d2); v3 *= act_bwd(p.act, d3);
+    float d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (vec) load8bf(p.dact_src + off, d);
+    else for (int j = 0; j < nv; ++j) d[j] = bf2f(p.dact_src[off + j]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= act_bwd(p.act, d[j]);
   } else if (p.act != VACNIC_ACT_NONE) {
-    v0 = act_fwd(p.act, v0); v1 = act_fwd(p.act, v1); v2 = act_fwd(p.act, v2); v3 = act_fwd(p.act, v3);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = act_fwd(p.act, v[j]);
   }
   if (p.residual) {
-    if (vec) {
-      u32x2 d = *(const u32x2*)(p.residual + off);
-      v0 += __uint_as_float(d[0] << 16); v1 += __uint_as_float(d[0] & 0xffff0000u);
-      v2 += __uint_as_float(d[1] << 16); v3 += __uint_as_float(d[1] & 0xffff0000u);
-    } else {
-      v0 += bf2f(p.residual[off]);
-      if (nv > 1) v1 += bf2f(p.residual[off + 1]);
-      if (nv > 2) v2 += bf2f(p.residual[off + 2]);
-      if (nv > 3) v3 += bf2f(p.residual[off + 3]);
-    }
+    float d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (vec) load8bf(p.residual + off, d);
+    else for (int j = 0; j < nv; ++j) d[j] = bf2f(p.residual[off + j]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += d[j];
   }
   if (p.out_mode == 0) {
     bf16_t* o = (bf16_t*)p.out + off;
-    if (vec) {
-      *(u32x2*)o = (u32x2){pack2bf(v0, v1), pack2bf(v2, v3)};
-    } else {
-      o[0] = f2bf(v0);
-      if (nv > 1) o[1] = f2bf(v1);
-      if (nv > 2) o[2] = f2bf(v2);
-      if (nv > 3) o[3] = f2bf(v3);
-    }
+    if (vec) store8bf(o, v);
+    else for (int j = 0; j < nv; ++j) o[j] = f2bf(v[j]);
   } else if (p.out_mode == 1) {
     float* o = (float*)p.out + off;
-    if (vec) {
-      *(f32x4*)o = (f32x4){v0, v1, v2, v3};
+    if (nv == 8 && (p.ldo & 3) == 0) {
+      *(f32x4*)o = (f32x4){v[0], v[1], v[2], v[3]};
+      *(f32x4*)(o + 4) = (f32x4){v[4], v[5], v[6], v[7]};
     } else {
-      o[0] = v0;
-      if (nv > 1) o[1] = v1;
-      if (nv > 2) o[2] = v2;
-      if (nv > 3) o[3] = v3;
+      for (int j = 0; j < nv; ++j) o[j] = v[j];
     }
   } else {
+    // accumulate, single K-split: no other workgroup of this launch touches these outputs -> vector read-modify-write
     float* o = (float*)p.out + off;
-    atomicAdd(o, v0);
-    if (nv > 1) atomicAdd(o + 1, v1);
-    if (nv > 2) atomicAdd(o + 2, v2);
-    if (nv > 3) atomicAdd(o + 3, v3);
+    if (nv == 8 && (p.ldo & 3) == 0) {
+      f32x4 a0 = *(f32x4*)o, a1 = *(f32x4*)(o + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { a0[j] += v[j]; a1[j] += v[4 + j]; }
+      *(f32x4*)o = a0; *(f32x4*)(o + 4) = a1;
+    } else {
+      for (int j = 0; j < nv; ++j) o[j] += v[j];
+    }
   }
 }
 
@@ -233,16 +229,59 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmP p) {
     __builtin_amdgcn_s_barrier();                         // all reads of buffer cur done
   }
 
-  // ---- epilogue: lane owns out[m][n..n+3], m = .. + (lane&15), n = .. + (lane>>4)*4 ----
+  // ---- epilogue: stage the fp32 C tile through LDS (the operand buffers are free now) in two 64-row
+  // passes, then every thread handles 8 consecutive n of one row: 16-byte coalesced traffic for the
+  // output, the saved pre-activation, the activation-backward source and the residual.
   const int lm = lane & 15, ln4 = (lane >> 4) * 4;
+  float* sc = (float*)smem;                 // [64][CLD] f32 = 33 KiB
+  constexpr int CLD = 132;
+  const bool vec_ok = (p.ldo & 7) == 0;
+  const bool add_bias = blockIdx.z == 0;
 #pragma unroll
-  for (int a = 0; a < 4; ++a) {
+  for (int pass = 0; pass < 2; ++pass) {
+    if (wm == pass) {
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int m = m0 + wm * 64 + a * 16 + lm;
-      const int n = n0 + wn * 64 + b * 16 + ln4;
-      if (m < p.M && n < p.N) store_quad(p, acc[b][a], m, n, blockIdx.z == 0);
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          *(f32x4*)(sc + (a * 16 + lm) * CLD + wn * 64 + b * 16 + ln4) = acc[b][a];
     }
+    __syncthreads();
+    if (p.out_mode == 2 && p.split_k > 1) {
+      // split-K accumulate: f32 atomics shaped as 256 contiguous bytes per wave-instruction (one row, 64
+      // consecutive columns) — the shape the memory-side atomic units run at full rate on
+#pragma unroll 1
+      for (int rr = 0; rr < 16; ++rr) {
+        const int row = wave * 16 + rr;
+        const int m = m0 + pass * 64 + row;
+        if (m >= p.M) break;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int n = n0 + h * 64 + lane;
+          if (n < p.N) {
+            float v = sc[row * CLD + h * 64 + lane] * p.alpha;
+            if (p.bias && add_bias) v += p.bias[n];
+            atomicAdd((float*)p.out + (size_t)m * p.ldo + n, v);
+          }
+        }
+      }
+      __syncthreads();
+      continue;
+    }
+#pragma unroll 1
+    for (int i = 0; i < 4; ++i) {
+      const int chunk = tid + 256 * i;
+      const int row = chunk >> 4, c8 = (chunk & 15) * 8;
+      const int m = m0 + pass * 64 + row, n = n0 + c8;
+      if (m < p.M && n < p.N) {
+        float v[8];
+        const f32x4 v0 = *(const f32x4*)(sc + row * CLD + c8), v1 = *(const f32x4*)(sc + row * CLD + c8 + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = v0[j]; v[4 + j] = v1[j]; }
+        epilogue8(p, v, m, n, add_bias, vec_ok);
+      }
+    }
+    __syncthreads();
   }
 }
 
