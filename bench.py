@@ -64,7 +64,7 @@ class GemmTimer:
             out = timer.orig(x, w, M, N, Kd, **kw)
             e.record()
             kind = ("T" if kw.get("x_kstrided") else "N") + ("T" if kw.get("w_kstrided") else "N")
-            timer.rec.append((kind, 2.0 * M * N * Kd, s, e))
+            timer.rec.append((kind, 2.0 * M * N * Kd, s, e, (M, N, Kd)))
             return out
         K.gemm = timed
 
@@ -74,9 +74,16 @@ class GemmTimer:
 
     def summary(self):
         agg = {}
-        for kind, fl, s, e in self.rec:
+        shapes = {}
+        for kind, fl, s, e, shp in self.rec:
+            dt = s.elapsed_time(e) * 1e-3
             a = agg.setdefault(kind, [0.0, 0.0, 0])
-            a[0] += fl; a[1] += s.elapsed_time(e) * 1e-3; a[2] += 1
+            a[0] += fl; a[1] += dt; a[2] += 1
+            b = shapes.setdefault((kind,) + shp, [0.0, 0.0, 0])
+            b[0] += fl; b[1] += dt; b[2] += 1
+        if os.environ.get("VACNIC_BENCH_SHAPES"):
+            for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:40]:
+                log(f"  gemm {k[0]} M={k[1]:6d} N={k[2]:6d} K={k[3]:6d} x{v[2]:3d}: {v[1]*1e3:7.2f} ms  {v[0]/v[1]/1e12:7.1f} TF/s")
         return agg
 
 

@@ -114,6 +114,23 @@ def test_gemm_wgrad_both_kstrided(K, M, N, K_, split):
     close(acc, ref, 2e-3, 2e-2 * math.sqrt(K_ / 256), "wgrad accumulate")
 
 
+@pytest.mark.parametrize("hint", [64, 128, 256])
+@pytest.mark.parametrize("M,N,K_", [(300, 520, 200), (1024, 768, 512), (257, 255 + 1, 64)])
+def test_gemm_all_layouts_both_tile_configs(K, hint, M, N, K_):
+    x = rnd(M, K_, seed=1); w = rnd(N, K_, scale=0.1, seed=2); b = rnd(N, dtype=torch.float32, seed=3)
+    ref = x.float() @ w.float().t()
+    tol = 2e-2 * math.sqrt(K_ / 64)
+    close(K.gemm(x, w, M, N, K_, bias=b, tile_hint=hint), ref + b, 1e-2, tol, f"NN hint {hint}")
+    wt = w.t().contiguous()                                   # [K_, N]: reduction-strided W
+    close(K.gemm(x, wt, M, N, K_, w_kstrided=True, tile_hint=hint), ref, 1e-2, tol, f"NT hint {hint}")
+    xt = torch.zeros(K_, (M + 7) // 8 * 8, device="cuda", dtype=torch.bfloat16); xt[:, :M] = x.t()
+    for split in (1, 2):
+        acc = torch.full((M, N), 2.0, device="cuda")
+        K.gemm(xt, wt, M, N, K_, out=acc, ldx=xt.shape[1], x_kstrided=True, w_kstrided=True, out_mode=2, split_k=split, tile_hint=hint)
+        close(acc, 2.0 + ref, 2e-3, tol, f"TT hint {hint} split {split}")
+    close(K.gemm(xt, w, M, N, K_, ldx=xt.shape[1], x_kstrided=True, tile_hint=hint), ref, 1e-2, tol, f"TN hint {hint}")
+
+
 # ------------------------------------------------------------------------------------------- attention
 def attn_ref(q, k, v, key_mask, causal, scale):
     B, Tq, H, hd = q.shape

@@ -28,21 +28,24 @@ def main():
     for name, M, N, Kd in [("xattn_kv 16384x1024x1024", 16384, 1024, 1024), ("qkv 16384x3072x1024", 16384, 3072, 1024),
                            ("fc1 16384x4096x1024", 16384, 4096, 1024), ("fc2 16384x1024x4096", 16384, 1024, 4096),
                            ("dec 2048x1024x1024", 2048, 1024, 1024), ("lmhead 2048x50267x1024", 2048, 50267, 1024),
-                           ("vit 8224x4096x1024", 8224, 4096, 1024)]:
+                           ("vit 8224x4096x1024", 8224, 4096, 1024), ("face 128x1024x3072", 128, 1024, 3072),
+                           ("img 640x1024x4096", 640, 1024, 4096), ("names 2560x1024x1024", 2560, 1024, 1024)]:
         x = r(M, Kd); w = r(N, Kd); b = torch.zeros(N, device=dev)
         ldo = (N + 31) // 32 * 32
         out = torch.empty(M, ldo, device=dev, dtype=torch.bfloat16)
-        t = timeit(lambda: K.gemm(x, w, M, N, Kd, bias=b, out=out, ldo=ldo))
-        res.append((f"gemm fwd {name}", t, 2 * M * N * Kd / t / 1e12, "TF/s"))
+        for hint in (0, 64, 128, 256):
+            t = timeit(lambda: K.gemm(x, w, M, N, Kd, bias=b, out=out, ldo=ldo, tile_hint=hint))
+            res.append((f"gemm fwd t{hint} {name}", t, 2 * M * N * Kd / t / 1e12, "TF/s"))
         if N <= 4096:
             dy = r(M, N)
             dx = torch.empty(M, Kd, device=dev, dtype=torch.bfloat16)
-            t = timeit(lambda: K.gemm(dy, w, M, Kd, N, out=dx, w_kstrided=True))
-            res.append((f"gemm dgrad {name}", t, 2 * M * N * Kd / t / 1e12, "TF/s"))
+            for hint in (0, 64, 128, 256):
+                t = timeit(lambda: K.gemm(dy, w, M, Kd, N, out=dx, w_kstrided=True, tile_hint=hint))
+                res.append((f"gemm dgrad t{hint} {name}", t, 2 * M * N * Kd / t / 1e12, "TF/s"))
             dw = torch.zeros(N, Kd, device=dev)
-            sp = K.wgrad_split(M, ((N + 127) // 128) * ((Kd + 127) // 128))
-            t = timeit(lambda: K.gemm(dy, x, N, Kd, M, out=dw, x_kstrided=True, w_kstrided=True, out_mode=2, split_k=sp))
-            res.append((f"gemm wgrad(split {sp}) {name}", t, 2 * M * N * Kd / t / 1e12, "TF/s"))
+            for hint, sp in ((128, K.wgrad_split(M, ((N + 127) // 128) * ((Kd + 127) // 128))), (256, max(1, 256 // (((N + 255) // 256) * ((Kd + 255) // 256)))), (256, max(1, 512 // (((N + 255) // 256) * ((Kd + 255) // 256))))):
+                t = timeit(lambda: K.gemm(dy, x, N, Kd, M, out=dw, x_kstrided=True, w_kstrided=True, out_mode=2, split_k=sp, tile_hint=hint))
+                res.append((f"gemm wgrad t{hint} split {sp} {name}", t, 2 * M * N * Kd / t / 1e12, "TF/s"))
     # attention
     for name, B, H, Tq, Tk, causal in [("enc self 512x512", 32, 16, 512, 512, False), ("enc cross 512x40", 32, 16, 512, 40, False),
                                        ("dec self 64x64", 32, 16, 64, 64, True), ("dec cross 64x512", 32, 16, 64, 512, False),

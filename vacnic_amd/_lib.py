@@ -37,7 +37,7 @@ def _struct(name, fields):
 GemmArgs = _struct("vacnic_gemm_args", [
     ("x", vp), ("w", vp), ("bias", vp), ("out", vp), ("preact", vp), ("dact_src", vp), ("residual", vp),
     ("M", i64), ("N", i64), ("K", i64), ("ldx", i64), ("ldw", i64), ("ldo", i64),
-    ("x_kstrided", i32), ("w_kstrided", i32), ("act", i32), ("out_mode", i32), ("split_k", i32), ("alpha", f32)])
+    ("x_kstrided", i32), ("w_kstrided", i32), ("act", i32), ("out_mode", i32), ("split_k", i32), ("alpha", f32), ("tile_hint", i32)])
 
 AttnFwdArgs = _struct("vacnic_attn_fwd_args", [
     ("q", vp), ("k", vp), ("v", vp), ("out", vp), ("lse", vp), ("key_mask", vp),

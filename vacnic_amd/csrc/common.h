@@ -63,25 +63,46 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ---- activations -----------------------------------------------------------------------------------
+// Epilogue-grade transcendental forms (v_exp_f32 / v_rcp_f32 based, no libm calls): the GEMM epilogue
+// applies them to every output element, so a libm erff/tanhf there costs more than the MFMA main loop
+// at K = 1024.  erf: Abramowitz-Stegun 7.1.26, |abs err| <= 1.5e-7 (three orders below bf16 rounding).
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// returns erf(|u|) and e = exp(-u*u) (shared with the Gaussian pdf of the GELU derivative)
+__device__ __forceinline__ float erf_abs(float au, float& e) {
+  const float t = fast_rcp(1.0f + 0.3275911f * au);
+  e = __expf(-au * au);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  return 1.0f - poly * e;
+}
+__device__ __forceinline__ float gelu_fwd(float x) {
+  float e;
+  const float er = erf_abs(fabsf(x) * 0.70710678118654752f, e);
+  return 0.5f * x * (1.0f + copysignf(er, x));
+}
+__device__ __forceinline__ float gelu_bwd(float x) {
+  float e;                                            // e = exp(-x^2/2)
+  const float er = erf_abs(fabsf(x) * 0.70710678118654752f, e);
+  return 0.5f * (1.0f + copysignf(er, x)) + x * 0.3989422804014327f * e;
+}
+__device__ __forceinline__ float tanh_fast(float x) {
+  const float e2 = __expf(-2.0f * fabsf(x));          // in (0, 1]: no overflow
+  return copysignf((1.0f - e2) * fast_rcp(1.0f + e2), x);
+}
 __device__ __forceinline__ float act_fwd(int act, float x) {
   switch (act) {
-    case VACNIC_ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
-    case VACNIC_ACT_TANH: return tanhf(x);
-    case VACNIC_ACT_QUICKGELU: return x / (1.0f + __expf(-1.702f * x));
+    case VACNIC_ACT_GELU: return gelu_fwd(x);
+    case VACNIC_ACT_TANH: return tanh_fast(x);
+    case VACNIC_ACT_QUICKGELU: return x * fast_rcp(1.0f + __expf(-1.702f * x));
     default: return x;
   }
 }
 // derivative w.r.t. the pre-activation x
 __device__ __forceinline__ float act_bwd(int act, float x) {
   switch (act) {
-    case VACNIC_ACT_GELU: {
-      float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-      float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
-      return cdf + x * pdf;
-    }
-    case VACNIC_ACT_TANH: { float t = tanhf(x); return 1.0f - t * t; }
+    case VACNIC_ACT_GELU: return gelu_bwd(x);
+    case VACNIC_ACT_TANH: { float t = tanh_fast(x); return 1.0f - t * t; }
     case VACNIC_ACT_QUICKGELU: {
-      float s = 1.0f / (1.0f + __expf(-1.702f * x));
+      float s = fast_rcp(1.0f + __expf(-1.702f * x));
       return s + 1.702f * x * s * (1.0f - s);
     }
     default: return 1.0f;

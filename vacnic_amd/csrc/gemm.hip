@@ -4,21 +4,25 @@
 // _linear_1up/down :587-588, _face_up/down :607-608, ner_map_up/down :594-595, prompt_mlp :1136,
 // visual_map :1144, lm_head :1885) and their dgrad / wgrad.
 //
-// Design (CDNA4): 128x128x64 block tile, 256 threads = 4 waves (2x2), each wave 64x64 as 4x4
-// v_mfma_f32_16x16x32_bf16 tiles.  Operands go HBM -> LDS with `buffer_load_dwordx4 ... lds`
-// (LDS-DMA, no VGPR round trip; the SRD range check zero-fills M/N/K edges).  The LDS image is
-// lane-linear per wave-instruction, so the bank-conflict XOR swizzle is applied to the per-lane
-// SOURCE address and again on the fragment read (guide rule 21).  An operand whose reduction index
-// is the strided one in memory (dgrad's W, wgrad's dY and X) is staged as [k][row] and read with
-// ds_read_b64_tr_b16 (hardware transpose), so no transposed copies are ever materialised.
-// MFMA A <- W rows, B <- X rows, i.e. the wave computes the C^T tile: each lane then owns 4
-// consecutive n of one m and stores 8/16 contiguous bytes.
+// Design (CDNA4): block tile BMxBNx64 with WMxWN waves, each wave a (BM/WM)x(BN/WN) sub-tile of
+// v_mfma_f32_16x16x32_bf16 tiles.  Two instantiations: 256x256 with 8 waves (2x4, 128x64 per wave,
+// 128 KiB LDS, one block per CU) for the large training GEMMs, 128x128 with 4 waves (2 blocks per CU)
+// when that fills the chip, and 64x128 with a 4-deep LDS ring for the small (latency-bound) problems.  Operands go HBM -> LDS with
+// `buffer_load_dwordx4 ... lds` (LDS-DMA, no VGPR round trip; the SRD range check zero-fills M/N/K
+// edges), double buffered, ONE barrier per K-tile: the loads of tile t+1 are issued before the MFMAs
+// of tile t and retired (vmcnt(0)) after them.  The LDS image is lane-linear per wave-instruction,
+// so the bank-conflict XOR swizzle is applied to the per-lane SOURCE address and again on the
+// fragment read (guide rule 21).  An operand whose reduction index is the strided one in memory
+// (dgrad's W, wgrad's dY and X) is staged as [k][row] and read with ds_read_b64_tr_b16 (hardware
+// transpose), so no transposed copies are ever materialised.  MFMA A <- W rows, B <- X rows, i.e. the
+// wave computes the C^T tile; the fp32 C tile is then staged through LDS so that every global access
+// of the epilogue (output, saved pre-activation, activation-backward source, residual) is a 16-byte
+// row-contiguous access and split-K atomics are 256 contiguous bytes per wave-instruction.
 #include "common.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = 128 * 64 * 2;      // 16 KiB, both layouts
+constexpr int BK = 64;
 constexpr int OOB = 0x7ffffff0;               // voffset beyond any (<2 GiB) buffer -> load returns 0
 
 struct GemmP {
@@ -35,15 +39,16 @@ struct GemmP {
 // f(k) of the K-strided swizzle: distinct for the 8 k-rows one tr-read half touches.
 __device__ __forceinline__ int fk(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
 
-// Issue the 4 LDS-DMA loads of this thread for one operand tile.
-//   KS=false: tile [128 rows][64 k], 128-B rows, chunk' = chunk ^ (row & 7)
-//   KS=true : tile [64 k][128 rows], 256-B rows, chunk' = chunk ^ (fk(k) << 1)
-template <bool KS>
+// Issue this wave's LDS-DMA loads for one operand tile of ROWS rows (x 64 k).
+//   KS=false: tile [ROWS][64 k], 128-B rows, chunk' = chunk ^ (row & 7); one 1-KiB piece = 8 rows
+//   KS=true : tile [64 k][ROWS], 2*ROWS-B rows, chunk' = chunk ^ (fk(k) << 1); one piece = 512/ROWS k-rows
+template <bool KS, int ROWS, int NWAVE>
 __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, int r0, int R,
                                            int k0, int kend, int ld, int wave, int lane) {
+  constexpr int PIECES = ROWS / 8 / NWAVE;      // 1-KiB pieces per wave
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int blk = wave * 4 + i;
+  for (int i = 0; i < PIECES; ++i) {
+    const int blk = wave * PIECES + i;
     int voff;
     if (!KS) {
       const int row = blk * 8 + (lane >> 3);
@@ -51,8 +56,9 @@ __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* ld
       const int gr = r0 + row, gk = k0 + lc * 8;
       voff = (gr < R && gk < kend) ? (int)(((unsigned)gr * (unsigned)ld + (unsigned)gk) * 2u) : OOB;
     } else {
-      const int k = blk * 4 + (lane >> 4);
-      const int lc = (lane & 15) ^ (fk(k) << 1);
+      constexpr int LPR = ROWS / 8;             // lanes (16-B chunks) per k-row
+      const int k = blk * (64 / LPR) + lane / LPR;
+      const int lc = (lane % LPR) ^ ((fk(k) << 1) & (LPR - 1));   // 64-row tiles have only 8 chunks per k-row
       const int gk = k0 + k, gr = r0 + lc * 8;
       voff = (gk < kend && gr < R) ? (int)(((unsigned)gk * (unsigned)ld + (unsigned)gr) * 2u) : OOB;
     }
@@ -61,7 +67,7 @@ __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* ld
 }
 
 // Fragment for MFMA 16x16x32: lane l gets element (row = rbase + (l&15), k = kk*32 + 8*(l>>4) + j), j=0..7.
-template <bool KS>
+template <bool KS, int ROWS>
 __device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int rbase, int kk, int lane) {
   if (!KS) {
     const int row = rbase + (lane & 15);
@@ -74,8 +80,8 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int rbase, int
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
       const int k = kk * 32 + 8 * g + 4 * hh + q;
-      const int phys = chunk ^ (fk(k) << 1);
-      const char* a = lds_tile + k * 256 + phys * 16 + (p & 1) * 8;
+      const int phys = chunk ^ ((fk(k) << 1) & (ROWS / 8 - 1));
+      const char* a = lds_tile + k * (ROWS * 2) + phys * 16 + (p & 1) * 8;
       bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)LDS_PTR(a));
       r[4 * hh + 0] = t[0]; r[4 * hh + 1] = t[1]; r[4 * hh + 2] = t[2]; r[4 * hh + 3] = t[3];
     }
@@ -157,13 +163,20 @@ __device__ __forceinline__ void epilogue8(const GemmP& p, float v[8], int m, int
   }
 }
 
-template <bool XKS, bool WKS>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmP p) {
+template <int N>
+__device__ __forceinline__ void wait_vm_lgkm() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
+
+template <int BM, int BN, int WM, int WN, int NSTAGE, bool XKS, bool WKS>
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
+  constexpr int NWAVE = WM * WN, NTHR = 64 * NWAVE;
+  constexpr int TM = BM / WM, TN = BN / WN;             // per-wave output sub-tile
+  constexpr int FA = TM / 16, FB = TN / 16;             // MFMA tiles per wave along m / n
+  constexpr int XT = BM * BK * 2, WT = BN * BK * 2, STAGE = XT + WT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave & 1, wn = wave >> 1;
+  const int wm = wave % WM, wn = wave / WM;
 
   // XCD-aware tile order: blocks b, b+8, ... share an XCD; give each XCD a contiguous run of tiles
   // (bijective for any tile count), n fastest so neighbours reuse the same X panel in their L2.
@@ -186,77 +199,89 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmP p) {
   const int RX = XKS ? ((p.M + 7) & ~7) : p.M;
   const int RW = WKS ? ((p.N + 7) & ~7) : p.N;
 
-  f32x4 acc[4][4];
+  f32x4 acc[FB][FA];
 #pragma unroll
-  for (int b = 0; b < 4; ++b)
+  for (int b = 0; b < FB; ++b)
 #pragma unroll
-    for (int a = 0; a < 4; ++a) acc[b][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < FA; ++a) acc[b][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // LDS: buffer b at smem + b*2*TILE_BYTES = {X tile, W tile}
-  if (ntile > 0) {
-    stage_tile<XKS>(xs, smem, m0, RX, kbeg, kend, p.ldx, wave, lane);
-    stage_tile<WKS>(ws, smem + TILE_BYTES, n0, RW, kbeg, kend, p.ldw, wave, lane);
+  // LDS: NSTAGE-deep ring, stage s at smem + s*STAGE = {X tile, W tile}.  Tiles t+1 .. t+NSTAGE-1 are in flight
+  // while tile t is multiplied; one barrier per K-tile.  Loads are issued unconditionally (a tile past kend is
+  // all out-of-range -> zero fill, never read) so the counted vmcnt below is a compile-time constant.
+  constexpr int LOADS = (BM + BN) / 8 / NWAVE;          // LDS-DMA instructions per wave per K-tile
+  static_assert(LOADS * (NSTAGE - 2) <= 63, "vmcnt immediate");
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s) {
+    stage_tile<XKS, BM, NWAVE>(xs, smem + s * STAGE, m0, RX, kbeg + s * BK, kend, p.ldx, wave, lane);
+    stage_tile<WKS, BN, NWAVE>(ws, smem + s * STAGE + XT, n0, RW, kbeg + s * BK, kend, p.ldw, wave, lane);
   }
+  wait_vm_lgkm<LOADS * (NSTAGE - 2)>();                  // tile 0 landed
+  __builtin_amdgcn_s_barrier();
+  int cur = 0, nxt = NSTAGE - 1;
   for (int t = 0; t < ntile; ++t) {
-    const int cur = t & 1;
-    char* xcur = smem + cur * (2 * TILE_BYTES);
-    char* wcur = xcur + TILE_BYTES;
-    if (t + 1 < ntile) {
-      // buffer cur^1 was last read in iteration t-1; every wave has passed that iteration's
-      // trailing barrier, so it is free to overwrite.
-      char* xnext = smem + (cur ^ 1) * (2 * TILE_BYTES);
-      stage_tile<XKS>(xs, xnext, m0, RX, kbeg + (t + 1) * BK, kend, p.ldx, wave, lane);
-      stage_tile<WKS>(ws, xnext + TILE_BYTES, n0, RW, kbeg + (t + 1) * BK, kend, p.ldw, wave, lane);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile t landed (this wave's 8 loads)
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    char* xcur = smem + cur * STAGE;
+    char* wcur = xcur + XT;
+    {
+      // ring slot `nxt` was last read in iteration t-1 and every wave has passed that iteration's barrier
+      char* xnext = smem + nxt * STAGE;
+      stage_tile<XKS, BM, NWAVE>(xs, xnext, m0, RX, kbeg + (t + NSTAGE - 1) * BK, kend, p.ldx, wave, lane);
+      stage_tile<WKS, BN, NWAVE>(ws, xnext + XT, n0, RW, kbeg + (t + NSTAGE - 1) * BK, kend, p.ldw, wave, lane);
     }
-    __builtin_amdgcn_s_barrier();                         // ... and every other wave's
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 xf[4], wf[4];
+      bf16x8 xf[FA], wf[FB];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) xf[a] = read_frag<XKS>(xcur, wm * 64 + a * 16, kk, lane);
+      for (int a = 0; a < FA; ++a) xf[a] = read_frag<XKS, BM>(xcur, wm * TM + a * 16, kk, lane);
 #pragma unroll
-      for (int b = 0; b < 4; ++b) wf[b] = read_frag<WKS>(wcur, wn * 64 + b * 16, kk, lane);
+      for (int b = 0; b < FB; ++b) wf[b] = read_frag<WKS, BN>(wcur, wn * TN + b * 16, kk, lane);
 #pragma unroll
-      for (int b = 0; b < 4; ++b)
+      for (int b = 0; b < FB; ++b)
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < FA; ++a)
           acc[b][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b], xf[a], acc[b][a], 0, 0, 0);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                         // all reads of buffer cur done
+    // tile t+1 landed (this wave's loads; newer tiles may still fly), LDS reads of this slot retired; then everyone's
+    wait_vm_lgkm<LOADS * (NSTAGE - 2)>();
+    __builtin_amdgcn_s_barrier();
+    cur = cur + 1 == NSTAGE ? 0 : cur + 1;
+    nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the (zero-fill) tail loads before LDS is reused
+  __builtin_amdgcn_s_barrier();
 
-  // ---- epilogue: stage the fp32 C tile through LDS (the operand buffers are free now) in two 64-row
+  // ---- epilogue: stage the fp32 C tile through LDS (the operand buffers are free now) in 64-row
   // passes, then every thread handles 8 consecutive n of one row: 16-byte coalesced traffic for the
   // output, the saved pre-activation, the activation-backward source and the residual.
   const int lm = lane & 15, ln4 = (lane >> 4) * 4;
-  float* sc = (float*)smem;                 // [64][CLD] f32 = 33 KiB
-  constexpr int CLD = 132;
+  float* sc = (float*)smem;                 // [64][CLD] f32
+  constexpr int CLD = BN + 4;
+  constexpr int PASSES = (BM + 63) / 64;
   const bool vec_ok = (p.ldo & 7) == 0;
   const bool add_bias = blockIdx.z == 0;
 #pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    if (wm == pass) {
+  for (int pass = 0; pass < PASSES; ++pass) {
+    // every 16-row group of this wave that falls into rows [pass*64, pass*64+64) of the block tile is deposited
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < FA; ++a) {
+      const int row0 = wm * TM + a * 16;
+      if (row0 / 64 == pass) {
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
-          *(f32x4*)(sc + (a * 16 + lm) * CLD + wn * 64 + b * 16 + ln4) = acc[b][a];
+        for (int b = 0; b < FB; ++b)
+          *(f32x4*)(sc + ((row0 & 63) + lm) * CLD + wn * TN + b * 16 + ln4) = acc[b][a];
+      }
     }
     __syncthreads();
     if (p.out_mode == 2 && p.split_k > 1) {
       // split-K accumulate: f32 atomics shaped as 256 contiguous bytes per wave-instruction (one row, 64
       // consecutive columns) — the shape the memory-side atomic units run at full rate on
+      constexpr int RPW = 64 / NWAVE;
 #pragma unroll 1
-      for (int rr = 0; rr < 16; ++rr) {
-        const int row = wave * 16 + rr;
+      for (int rr = 0; rr < RPW; ++rr) {
+        const int row = wave * RPW + rr;
         const int m = m0 + pass * 64 + row;
         if (m >= p.M) break;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < BN / 64; ++h) {
           const int n = n0 + h * 64 + lane;
           if (n < p.N) {
             float v = sc[row * CLD + h * 64 + lane] * p.alpha;
@@ -268,10 +293,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmP p) {
       __syncthreads();
       continue;
     }
+    constexpr int CPR = BN / 8;               // 8-wide chunks per row
 #pragma unroll 1
-    for (int i = 0; i < 4; ++i) {
-      const int chunk = tid + 256 * i;
-      const int row = chunk >> 4, c8 = (chunk & 15) * 8;
+    for (int chunk = tid; chunk < 64 * CPR; chunk += NTHR) {
+      const int row = chunk / CPR, c8 = (chunk % CPR) * 8;
       const int m = m0 + pass * 64 + row, n = n0 + c8;
       if (m < p.M && n < p.N) {
         float v[8];
@@ -285,6 +310,31 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmP p) {
   }
 }
 
+template <int BM, int BN, int WM, int WN, int NSTAGE>
+int launch_gemm(const GemmP& p0, bool xks, bool wks, int zsplits, hipStream_t s) {
+  GemmP p = p0;
+  p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
+  dim3 grid(p.tiles_m * p.tiles_n, 1, zsplits), block(64 * WM * WN);
+  constexpr size_t lds = NSTAGE * (BM + BN) * BK * 2;
+  static_assert(lds >= 64 * (BN + 4) * 4, "epilogue staging must fit in the operand buffers");
+#define VAC_LAUNCH(XK, WK)                                                                            \
+  do {                                                                                                \
+    auto kern = gemm_kernel<BM, BN, WM, WN, NSTAGE, XK, WK>;                                                  \
+    if (lds > 65536) {                                                                                \
+      static bool once = false;                                                                       \
+      if (!once) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; } \
+    }                                                                                                 \
+    hipLaunchKernelGGL(kern, grid, block, lds, s, p);                                                 \
+  } while (0)
+  if (!xks && !wks) VAC_LAUNCH(false, false);
+  else if (!xks && wks) VAC_LAUNCH(false, true);
+  else if (xks && wks) VAC_LAUNCH(true, true);
+  else VAC_LAUNCH(true, false);
+#undef VAC_LAUNCH
+  VLAUNCH_CHECK();
+  return VACNIC_OK;
+}
+
 }  // namespace
 
 extern "C" int vacnic_gemm_bf16(const vacnic_gemm_args* a, void* stream) {
@@ -296,6 +346,7 @@ extern "C" int vacnic_gemm_bf16(const vacnic_gemm_args* a, void* stream) {
   VCHECK(a->out_mode >= 0 && a->out_mode <= 2, VACNIC_BAD_DTYPE, "gemm: bad out_mode %d", a->out_mode);
   const int split = a->split_k < 1 ? 1 : a->split_k;
   VCHECK(split == 1 || a->out_mode == 2, VACNIC_UNSUPPORTED, "gemm: split_k needs out_mode 2");
+  VCHECK(a->bias == nullptr || aligned16(a->bias), VACNIC_MISALIGNED, "gemm: bias must be 16-byte aligned");
   VCHECK(a->ldo >= a->N, VACNIC_BAD_SHAPE, "gemm: ldo < N");
   if (a->x_kstrided) VCHECK(a->ldx >= ((a->M + 7) & ~7LL), VACNIC_BAD_SHAPE, "gemm: ldx too small for K-strided X");
   else VCHECK(a->ldx >= ((a->K + 7) & ~7LL), VACNIC_BAD_SHAPE, "gemm: ldx < round_up(K, 8) for K-contiguous X");
@@ -319,16 +370,20 @@ extern "C" int vacnic_gemm_bf16(const vacnic_gemm_args* a, void* stream) {
   kps = (kps + BK - 1) / BK * BK;
   p.k_per_split = kps;
   const int zsplits = (int)((a->K + kps - 1) / kps);
+  p.split_k = zsplits;
   p.alpha = a->alpha;
   p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
-  p.tiles_m = (int)((a->M + BM - 1) / BM); p.tiles_n = (int)((a->N + BN - 1) / BN);
-  dim3 grid(p.tiles_m * p.tiles_n, 1, zsplits), block(256);
-  const size_t lds = 4 * TILE_BYTES;
+  p.tiles_m = p.tiles_n = 0;
   hipStream_t s = (hipStream_t)stream;
-  if (!a->x_kstrided && !a->w_kstrided) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, lds, s, p);
-  else if (!a->x_kstrided && a->w_kstrided) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, lds, s, p);
-  else if (a->x_kstrided && a->w_kstrided) hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, lds, s, p);
-  else hipLaunchKernelGGL((gemm_kernel<true, false>), grid, block, lds, s, p);
-  VLAUNCH_CHECK();
-  return VACNIC_OK;
+  // tile configuration: 256x256 (8 waves, 1 block/CU) when those tiles (times the K-splits) can occupy most of
+  // the 256 CUs; 128x128 (2 blocks/CU) when that fills the chip; otherwise 64x128 with a 4-deep LDS-DMA ring —
+  // small problems put at most one workgroup on a CU, so load latency must be hidden inside the workgroup.
+  const int64_t t256 = ((a->M + 255) / 256) * ((a->N + 255) / 256) * zsplits;
+  const int64_t t128 = ((a->M + 127) / 128) * ((a->N + 127) / 128) * zsplits;
+  const int force = a->tile_hint;
+  const bool big = force == 256 || (force == 0 && a->M >= 256 && a->N >= 256 && t256 >= 192);
+  const bool mid = force == 128 || (force == 0 && t128 >= 384);
+  if (big) return launch_gemm<256, 256, 2, 4, 2>(p, a->x_kstrided, a->w_kstrided, zsplits, s);
+  if (mid) return launch_gemm<128, 128, 2, 2, 2>(p, a->x_kstrided, a->w_kstrided, zsplits, s);
+  return launch_gemm<64, 128, 2, 2, 4>(p, a->x_kstrided, a->w_kstrided, zsplits, s);
 }

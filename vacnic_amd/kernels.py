@@ -35,7 +35,7 @@ def _row_stride(t):
 
 # ------------------------------------------------------------------------------------------------ GEMM
 def gemm(x, w, M, N, K, *, bias=None, out=None, ldx=None, ldw=None, ldo=None, x_kstrided=False, w_kstrided=False,
-         act=None, out_mode=0, split_k=1, alpha=1.0, preact=None, dact_src=None, residual=None):
+         act=None, out_mode=0, split_k=1, alpha=1.0, preact=None, dact_src=None, residual=None, tile_hint=0):
     """out[m][n] = epi(alpha * sum_k X(m,k) W(n,k) + bias[n]) — see include/vacnic_hip.h."""
     if out is None:
         out = torch.empty((M, N), device=x.device, dtype=BF16 if out_mode == 0 else torch.float32)
@@ -45,7 +45,7 @@ def gemm(x, w, M, N, K, *, bias=None, out=None, ldx=None, ldw=None, ldo=None, x_
     call_struct("vacnic_gemm_bf16", stream=_stream(), x=_p(x), w=_p(w), bias=_p(bias), out=_p(out), preact=_p(preact),
                 dact_src=_p(dact_src), residual=_p(residual), M=M, N=N, K=K, ldx=ldx, ldw=ldw, ldo=ldo,
                 x_kstrided=int(x_kstrided), w_kstrided=int(w_kstrided), act=ACT[act], out_mode=out_mode,
-                split_k=split_k, alpha=alpha)
+                split_k=split_k, alpha=alpha, tile_hint=tile_hint)
     return out
 
 
