@@ -188,6 +188,7 @@ def main():
             timer.install()
         out4 = train_step(net, guide, opt, batches[(a.warmup + i) % nb], args)
     timer.remove()
+    host_dt = time.perf_counter() - t0           # host-side enqueue time of the K steps (GPU may still be running)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -198,7 +199,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     losses = out4.tolist()
-    log(f"timed {a.steps} steps in {dt:.3f}s; losses {losses}")
+    log(f"timed {a.steps} steps in {dt:.3f}s (host enqueue {host_dt / a.steps * 1e3:.1f} ms/step); losses {losses}")
     if rank == 0:
         agg = timer.summary()
         dom = max(agg.items(), key=lambda kv: kv[1][1]) if agg else None
@@ -222,6 +223,7 @@ def main():
                "config": {"workload": f"BASELINE configs[{1 if world == 1 else 2}]: BART-large + CLIP ViT-L/14 full VACNIC (clipcap P=20, SECLA, CoLaM a=0.5 m=1.0), "
                                       f"224x224 image, {S}-token article, {T}-token caption, per-GPU batch {B}, dropout 0.1, fp32 master + bf16 compute",
                           "global_batch": B * world, "seq_len": S, "caption_len": T, "parallelism": f"dp{world}"},
+               "host_enqueue_ms_per_step": round(host_dt / a.steps * 1e3, 2),
                "step_tflops_per_gpu": round(value / world * gf / 1e3, 1) if gf else None,
                "step_mfma_frac": round(value / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4) if gf else None,
                "losses_last_step": {"total": losses[0], "txt": losses[1], "secla": losses[2], "colam": losses[3]},

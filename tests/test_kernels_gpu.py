@@ -114,7 +114,7 @@ def test_gemm_wgrad_both_kstrided(K, M, N, K_, split):
     close(acc, ref, 2e-3, 2e-2 * math.sqrt(K_ / 256), "wgrad accumulate")
 
 
-@pytest.mark.parametrize("hint", [64, 128, 256])
+@pytest.mark.parametrize("hint", [64, 128, 256, 257])
 @pytest.mark.parametrize("M,N,K_", [(300, 520, 200), (1024, 768, 512), (257, 255 + 1, 64)])
 def test_gemm_all_layouts_both_tile_configs(K, hint, M, N, K_):
     x = rnd(M, K_, seed=1); w = rnd(N, K_, scale=0.1, seed=2); b = rnd(N, dtype=torch.float32, seed=3)

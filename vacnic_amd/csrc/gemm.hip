@@ -39,21 +39,32 @@ struct GemmP {
 // f(k) of the K-strided swizzle: distinct for the 8 k-rows one tr-read half touches.
 __device__ __forceinline__ int fk(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
 
-// Issue this wave's LDS-DMA loads for one operand tile of ROWS rows (x 64 k).
-//   KS=false: tile [ROWS][64 k], 128-B rows, chunk' = chunk ^ (row & 7); one 1-KiB piece = 8 rows
-//   KS=true : tile [64 k][ROWS], 2*ROWS-B rows, chunk' = chunk ^ (fk(k) << 1); one piece = 512/ROWS k-rows
-template <bool KS, int ROWS, int NWAVE>
+// Issue this wave's LDS-DMA loads for one operand tile of ROWS rows x BKT k (BKT = 64 or 32).
+//   KS=false, BKT=64: tile [ROWS][64 k], 128-B LDS rows, chunk' = chunk ^ (row & 7); one 1-KiB piece = 8 rows
+//   KS=false, BKT=32: two 64-B global rows share one 128-B LDS row R = row/2 (chunk = (row&1)*4 + kchunk),
+//                     chunk' = chunk ^ (R & 7); one piece = 16 rows
+//   KS=true : tile [BKT k][ROWS], 2*ROWS-B rows, chunk' = chunk ^ swz(k); one piece = 512/ROWS k-rows
+template <bool KS, int ROWS, int BKT, int NWAVE>
 __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, int r0, int R,
                                            int k0, int kend, int ld, int wave, int lane) {
-  constexpr int PIECES = ROWS / 8 / NWAVE;      // 1-KiB pieces per wave
+  constexpr int PIECES = ROWS * BKT * 2 / 1024 / NWAVE;      // 1-KiB pieces per wave
+  static_assert(PIECES >= 1, "tile too small for this wave count");
 #pragma unroll
   for (int i = 0; i < PIECES; ++i) {
     const int blk = wave * PIECES + i;
     int voff;
     if (!KS) {
-      const int row = blk * 8 + (lane >> 3);
-      const int lc = (lane & 7) ^ (row & 7);
-      const int gr = r0 + row, gk = k0 + lc * 8;
+      int row, kch;
+      if (BKT == 64) {
+        row = blk * 8 + (lane >> 3);
+        kch = (lane & 7) ^ (row & 7);
+      } else {
+        const int Rl = blk * 8 + (lane >> 3);
+        const int lc = (lane & 7) ^ (Rl & 7);
+        row = 2 * Rl + (lc >> 2);
+        kch = lc & 3;
+      }
+      const int gr = r0 + row, gk = k0 + kch * 8;
       voff = (gr < R && gk < kend) ? (int)(((unsigned)gr * (unsigned)ld + (unsigned)gk) * 2u) : OOB;
     } else {
       constexpr int LPR = ROWS / 8;             // lanes (16-B chunks) per k-row
@@ -67,12 +78,18 @@ __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* ld
 }
 
 // Fragment for MFMA 16x16x32: lane l gets element (row = rbase + (l&15), k = kk*32 + 8*(l>>4) + j), j=0..7.
-template <bool KS, int ROWS>
+template <bool KS, int ROWS, int BKT>
 __device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int rbase, int kk, int lane) {
   if (!KS) {
     const int row = rbase + (lane & 15);
-    const int chunk = kk * 4 + (lane >> 4);
-    return *(const bf16x8*)(lds_tile + row * 128 + ((chunk ^ (row & 7)) << 4));
+    if (BKT == 64) {
+      const int chunk = kk * 4 + (lane >> 4);
+      return *(const bf16x8*)(lds_tile + row * 128 + ((chunk ^ (row & 7)) << 4));
+    } else {
+      const int Rl = row >> 1;
+      const int chunk = (row & 1) * 4 + (lane >> 4);
+      return *(const bf16x8*)(lds_tile + Rl * 128 + ((chunk ^ (Rl & 7)) << 4));
+    }
   } else {
     const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
     const int chunk = (rbase >> 3) + (p >> 1);
@@ -166,12 +183,12 @@ __device__ __forceinline__ void epilogue8(const GemmP& p, float v[8], int m, int
 template <int N>
 __device__ __forceinline__ void wait_vm_lgkm() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, bool XKS, bool WKS>
+template <int BM, int BN, int WM, int WN, int BKT, int NSTAGE, bool XKS, bool WKS>
 __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
   constexpr int NWAVE = WM * WN, NTHR = 64 * NWAVE;
   constexpr int TM = BM / WM, TN = BN / WN;             // per-wave output sub-tile
   constexpr int FA = TM / 16, FB = TN / 16;             // MFMA tiles per wave along m / n
-  constexpr int XT = BM * BK * 2, WT = BN * BK * 2, STAGE = XT + WT;
+  constexpr int XT = BM * BKT * 2, WT = BN * BKT * 2, STAGE = XT + WT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -190,7 +207,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
   const int m0 = tm * BM, n0 = tn * BN;
   const int kbeg = blockIdx.z * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);
-  const int ntile = (kend - kbeg + BK - 1) / BK;
+  const int ntile = (kend - kbeg + BKT - 1) / BKT;
 
   __amdgpu_buffer_rsrc_t xs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
@@ -208,12 +225,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
   // LDS: NSTAGE-deep ring, stage s at smem + s*STAGE = {X tile, W tile}.  Tiles t+1 .. t+NSTAGE-1 are in flight
   // while tile t is multiplied; one barrier per K-tile.  Loads are issued unconditionally (a tile past kend is
   // all out-of-range -> zero fill, never read) so the counted vmcnt below is a compile-time constant.
-  constexpr int LOADS = (BM + BN) / 8 / NWAVE;          // LDS-DMA instructions per wave per K-tile
+  constexpr int LOADS = (BM + BN) * BKT * 2 / 1024 / NWAVE;   // LDS-DMA instructions per wave per K-tile
   static_assert(LOADS * (NSTAGE - 2) <= 63, "vmcnt immediate");
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s) {
-    stage_tile<XKS, BM, NWAVE>(xs, smem + s * STAGE, m0, RX, kbeg + s * BK, kend, p.ldx, wave, lane);
-    stage_tile<WKS, BN, NWAVE>(ws, smem + s * STAGE + XT, n0, RW, kbeg + s * BK, kend, p.ldw, wave, lane);
+    stage_tile<XKS, BM, BKT, NWAVE>(xs, smem + s * STAGE, m0, RX, kbeg + s * BKT, kend, p.ldx, wave, lane);
+    stage_tile<WKS, BN, BKT, NWAVE>(ws, smem + s * STAGE + XT, n0, RW, kbeg + s * BKT, kend, p.ldw, wave, lane);
   }
   wait_vm_lgkm<LOADS * (NSTAGE - 2)>();                  // tile 0 landed
   __builtin_amdgcn_s_barrier();
@@ -224,16 +241,16 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
     {
       // ring slot `nxt` was last read in iteration t-1 and every wave has passed that iteration's barrier
       char* xnext = smem + nxt * STAGE;
-      stage_tile<XKS, BM, NWAVE>(xs, xnext, m0, RX, kbeg + (t + NSTAGE - 1) * BK, kend, p.ldx, wave, lane);
-      stage_tile<WKS, BN, NWAVE>(ws, xnext + XT, n0, RW, kbeg + (t + NSTAGE - 1) * BK, kend, p.ldw, wave, lane);
+      stage_tile<XKS, BM, BKT, NWAVE>(xs, xnext, m0, RX, kbeg + (t + NSTAGE - 1) * BKT, kend, p.ldx, wave, lane);
+      stage_tile<WKS, BN, BKT, NWAVE>(ws, xnext + XT, n0, RW, kbeg + (t + NSTAGE - 1) * BKT, kend, p.ldw, wave, lane);
     }
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+    for (int kk = 0; kk < BKT / 32; ++kk) {
       bf16x8 xf[FA], wf[FB];
 #pragma unroll
-      for (int a = 0; a < FA; ++a) xf[a] = read_frag<XKS, BM>(xcur, wm * TM + a * 16, kk, lane);
+      for (int a = 0; a < FA; ++a) xf[a] = read_frag<XKS, BM, BKT>(xcur, wm * TM + a * 16, kk, lane);
 #pragma unroll
-      for (int b = 0; b < FB; ++b) wf[b] = read_frag<WKS, BN>(wcur, wn * TN + b * 16, kk, lane);
+      for (int b = 0; b < FB; ++b) wf[b] = read_frag<WKS, BN, BKT>(wcur, wn * TN + b * 16, kk, lane);
 #pragma unroll
       for (int b = 0; b < FB; ++b)
 #pragma unroll
@@ -310,16 +327,16 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE>
+template <int BM, int BN, int WM, int WN, int BKT, int NSTAGE>
 int launch_gemm(const GemmP& p0, bool xks, bool wks, int zsplits, hipStream_t s) {
   GemmP p = p0;
   p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
   dim3 grid(p.tiles_m * p.tiles_n, 1, zsplits), block(64 * WM * WN);
-  constexpr size_t lds = NSTAGE * (BM + BN) * BK * 2;
+  constexpr size_t lds = NSTAGE * (BM + BN) * BKT * 2;
   static_assert(lds >= 64 * (BN + 4) * 4, "epilogue staging must fit in the operand buffers");
 #define VAC_LAUNCH(XK, WK)                                                                            \
   do {                                                                                                \
-    auto kern = gemm_kernel<BM, BN, WM, WN, NSTAGE, XK, WK>;                                                  \
+    auto kern = gemm_kernel<BM, BN, WM, WN, BKT, NSTAGE, XK, WK>;                                                  \
     if (lds > 65536) {                                                                                \
       static bool once = false;                                                                       \
       if (!once) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; } \
@@ -367,7 +384,7 @@ extern "C" int vacnic_gemm_bf16(const vacnic_gemm_args* a, void* stream) {
   p.ldx = (int)a->ldx; p.ldw = (int)a->ldw; p.ldo = (int)a->ldo;
   p.act = a->act; p.out_mode = a->out_mode; p.split_k = split;
   int kps = (int)((a->K + split - 1) / split);
-  kps = (kps + BK - 1) / BK * BK;
+  kps = (kps + BK - 1) / BK * BK;               // multiple of 64: valid for both K-tile depths
   p.k_per_split = kps;
   const int zsplits = (int)((a->K + kps - 1) / kps);
   p.split_k = zsplits;
@@ -383,7 +400,8 @@ extern "C" int vacnic_gemm_bf16(const vacnic_gemm_args* a, void* stream) {
   const int force = a->tile_hint;
   const bool big = force == 256 || (force == 0 && a->M >= 256 && a->N >= 256 && t256 >= 192);
   const bool mid = force == 128 || (force == 0 && t128 >= 384);
-  if (big) return launch_gemm<256, 256, 2, 4, 2>(p, a->x_kstrided, a->w_kstrided, zsplits, s);
-  if (mid) return launch_gemm<128, 128, 2, 2, 2>(p, a->x_kstrided, a->w_kstrided, zsplits, s);
-  return launch_gemm<64, 128, 2, 2, 4>(p, a->x_kstrided, a->w_kstrided, zsplits, s);
+  if (force == 257) return launch_gemm<256, 128, 2, 2, 32, 3>(p, a->x_kstrided, a->w_kstrided, zsplits, s);   // experimental: 2 blocks/CU
+  if (big) return launch_gemm<256, 256, 2, 4, 64, 2>(p, a->x_kstrided, a->w_kstrided, zsplits, s);
+  if (mid) return launch_gemm<128, 128, 2, 2, 64, 2>(p, a->x_kstrided, a->w_kstrided, zsplits, s);
+  return launch_gemm<64, 128, 2, 2, 64, 4>(p, a->x_kstrided, a->w_kstrided, zsplits, s);
 }

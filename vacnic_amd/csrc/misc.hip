@@ -130,7 +130,8 @@ __global__ __launch_bounds__(256) void argmax_kernel(const void* __restrict__ lo
   if (threadIdx.x == 0) out[r] = bi[0];
 }
 
-// dbias[n] += sum_m dy[m][n]; block = 64 column-chunks (512 cols) x 4 row groups
+// dbias[n] += sum_m dy[m][n]; block = 64 column-chunks (512 cols) x 4 row groups over a 32..64-row slab, so a
+// [16384 x 1024] gradient spreads over ~1000 workgroups with 8 independent 16-byte loads in flight per thread
 __global__ __launch_bounds__(256) void bias_grad_kernel(const bf16_t* __restrict__ dy, float* __restrict__ dbias, long M, int N,
                                                         long ldy, int rows_per_block) {
   __shared__ float red[4][64 * 8 + 1];
@@ -142,7 +143,17 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const bf16_t* __restrict
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
   if (c * 8 + 8 <= N) {
-    for (long r = r0 + rg; r < r1; r += 4) {
+    long r = r0 + rg;
+    for (; r + 28 < r1; r += 32) {                // 8 rows per trip, all loads issued before the adds
+      u32x4 d[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) d[u] = *(const u32x4*)(dy + (r + 4 * u) * ldy + c * 8);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { acc[2 * k] += __uint_as_float(d[u][k] << 16); acc[2 * k + 1] += __uint_as_float(d[u][k] & 0xffff0000u); }
+    }
+    for (; r < r1; r += 4) {
       const u32x4 d = *(const u32x4*)(dy + r * ldy + c * 8);
 #pragma unroll
       for (int k = 0; k < 4; ++k) { acc[2 * k] += __uint_as_float(d[k] << 16); acc[2 * k + 1] += __uint_as_float(d[k] & 0xffff0000u); }
@@ -244,10 +255,12 @@ extern "C" int vacnic_bias_grad(const void* dy, float* dbias, int64_t M, int64_t
   VCHECK((ldy & 7) == 0 && aligned16(dy), VACNIC_MISALIGNED, "bias_grad: dy rows must be 16-byte aligned");
   if (M == 0 || N == 0) return VACNIC_OK;
   const int cb = (int)((N + 511) / 512);
-  int rb = (int)((M + 255) / 256);
-  if (rb > 256) rb = 256;
+  // ~64-row slabs, but keep the grid around 2k workgroups for very tall inputs
+  long rb = (M + 63) / 64;
+  const long cap = 2048 / cb > 1 ? 2048 / cb : 1;
+  if (rb > cap) rb = cap;
   const int rows_per_block = (int)((M + rb - 1) / rb);
-  hipLaunchKernelGGL(bias_grad_kernel, dim3(cb, rb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, dbias, (long)M,
+  hipLaunchKernelGGL(bias_grad_kernel, dim3(cb, (unsigned)rb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, dbias, (long)M,
                      (int)N, (long)ldy, rows_per_block);
   VLAUNCH_CHECK();
   return VACNIC_OK;
