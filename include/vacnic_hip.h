@@ -268,6 +268,16 @@ int vacnic_bias_grad(const void* dy, float* dbias, int64_t M, int64_t N, int64_t
 /* out = a + b (bf16) — gradient fan-in where a tensor feeds two consumers */
 int vacnic_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);
 
+/* ---- decode (transformers 4.18 GenerationMixin.beam_search driven at TRAIN:513-520, DDPINF:758-842) ---- */
+/* Per beam row: log_softmax(logits[:V]) -> NoRepeatNGram bans (bans int32 [R][n_ban], -1 = none) -> MinLength
+ * (suppress_eos) -> ForcedEOS (forced_token >= 0: that token scores 0, all others -inf) -> + beam_scores[r] ->
+ * top-K (sorted, ties broken towards the lower token id).  top_val f32 [R][K], top_idx int32 [R][K]. */
+int vacnic_beam_topk(const void* logits, const float* beam_scores, const int32_t* bans, int32_t n_ban, int32_t eos,
+                     int32_t suppress_eos, int32_t forced_token, float* top_val, int32_t* top_idx, int64_t R, int64_t V,
+                     int64_t ldl, int32_t K, int32_t logits_f32, void* stream);
+/* dst[r] = src[idx[r]] for rows of row_bytes (multiple of 16): KV-cache beam reorder (_reorder_cache, MFULL:2066-2074). */
+int vacnic_gather_rows(const void* src, void* dst, const int64_t* idx, int64_t rows, int64_t row_bytes, void* stream);
+
 /* ---- hardware probes (tests only): verify MFMA / ds_read_tr lane maps assumed by the kernels -- */
 int vacnic_probe_layouts(float* out, const float* src128, int64_t n_out, void* stream);
 

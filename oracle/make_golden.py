@@ -186,6 +186,38 @@ def run_mvis_case(name, mvis, train, cfg, B, S, T):
     print(name, rec["txt"])
 
 
+GEN_CASES = [  # (num_beams, length_penalty, extra generate kwargs)
+    (5, 2.0, {}), (5, 1.0, {}), (1, 1.0, dict(min_length=4)), (5, 1.0, dict(min_length=4)),
+    (4, 2.0, dict(min_length=3, no_repeat_ngram_size=2)), (3, 0.5, dict(min_length=5, no_repeat_ngram_size=3, early_stopping=True))]
+
+
+def run_generate_case(mfull, train):
+    """Beam search of transformers 5.15 (GenerationMixin, cache-less) over the REFERENCE model's logits: pins the
+    oracle's restatement of the 4.18 beam-search bookkeeping (generate lives in the un-vendored HF package)."""
+    from transformers import GenerationMixin
+    cfg = small_cfg(encoder_layers=1, decoder_layers=1)
+    sd = synthetic.make_state_dict(synthetic.mmbart_param_shapes(cfg), seed=1)
+
+    class Oracle(mfull.BartForMultiModalGeneration, GenerationMixin):
+        pass
+    orig = mfull.BartForMultiModalGeneration
+    mfull.BartForMultiModalGeneration = Oracle
+    m = build_ref_model(mfull, cfg, sd)
+    mfull.BartForMultiModalGeneration = orig
+    batch = synthetic.make_batch(cfg, 2, S=24, T=8, F=2, seed=9, image_size=32)
+    src = batch["article_ids"]; mask = train.create_src_mask_bart(src)
+    img = synthetic._normal("img_cls", (2, 768), 1.0, 3)
+    kw = dict(image_features=img, face_features=batch["face_emb"], face_mask=train.create_src_mask_bart(batch["face_emb"][:, :, -1]),
+              name_ids=batch["names_art_ids"], name_mask=train.create_src_mask_bart(batch["names_art_ids"]), add_ner_ffn=True)
+    rec = {}
+    for i, (nb, lp, extra) in enumerate(GEN_CASES):
+        out = m.generate(input_ids=src, attention_mask=mask, num_beams=nb, max_length=12, length_penalty=lp, use_cache=False,
+                         do_sample=False, **extra, **kw).sequences
+        rec[f"seq{i}"] = out.numpy()
+        print("generate", nb, lp, extra, out.tolist())
+    np.savez_compressed(os.path.join(OUT, "generate_small.npz"), **rec)
+
+
 def run_helpers(train, BatchSoftmax):
     g = torch.Generator().manual_seed(5)
     ids = torch.tensor([[0, 5, 6, 2, 1], [0, 9, 2, 1, 1], [0, 7, -100, 2, 1]])
@@ -253,6 +285,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     mfull, mvis, train, BatchSoftmax = import_reference()
     run_helpers(train, BatchSoftmax)
+    run_generate_case(mfull, train)
     run_clip_crosscheck()
     run_full_case("mfull_d768", mfull, train, BatchSoftmax, small_cfg(), B=3, S=48, T=12, F=3)
     run_full_case("mfull_d1024", mfull, train, BatchSoftmax,

@@ -319,3 +319,130 @@ def greedy_decode(sd, cfg, input_ids, attention_mask, image_features, max_length
         nxt = Fn.linear(h[:, -1], sd["model.shared.weight"]).argmax(-1)
         ids = torch.cat([ids, nxt[:, None]], dim=1)
     return ids
+
+
+# ------------------------------------------------------------------------------------ beam search (config 5)
+class _BeamHyps:
+    """transformers==4.18 BeamHypotheses (generation_beam_search.py): n-best list scored by
+    sum_logprobs / len(hyp)**length_penalty, where len counts the decoder start token and NOT the closing EOS.
+    norm="v5" divides by (len - 1)**length_penalty instead (newer transformers subtract the 1-token decoder prompt);
+    that switch exists only to pin this restatement against the transformers 5.15 run in oracle/make_golden.py."""
+
+    def __init__(self, num_beams, length_penalty, early_stopping, norm="v4.18"):
+        self.n, self.lp, self.early, self.norm = num_beams, length_penalty, early_stopping, norm
+        self.beams, self.worst = [], 1e9
+
+    def _len(self, L):
+        return L if self.norm == "v4.18" else max(L - 1, 1)
+
+    def add(self, hyp, sum_logprobs):
+        score = sum_logprobs / (self._len(len(hyp)) ** self.lp)
+        if len(self.beams) < self.n or score > self.worst:
+            self.beams.append((score, list(hyp)))
+            if len(self.beams) > self.n:
+                srt = sorted((s, i) for i, (s, _) in enumerate(self.beams))
+                del self.beams[srt[0][1]]
+                self.worst = srt[1][0]
+            else:
+                self.worst = min(score, self.worst)
+
+    def is_done(self, best_sum_logprobs, cur_len):
+        if len(self.beams) < self.n:
+            return False
+        if self.early:
+            return True
+        return self.worst >= best_sum_logprobs / self._len(cur_len) ** self.lp
+
+
+def banned_ngram_tokens(seq, n):
+    """NoRepeatNGramLogitsProcessor: tokens that would complete an n-gram already present in seq."""
+    if n <= 0 or len(seq) + 1 < n:
+        return []
+    prefix = tuple(seq[len(seq) - (n - 1):]) if n > 1 else ()
+    return [seq[i + n - 1] for i in range(len(seq) - n + 1) if tuple(seq[i:i + n - 1]) == prefix]
+
+
+def beam_search_bookkeeping(step_logprobs_fn, B, num_beams, max_length, eos, pad, start, length_penalty=1.0,
+                            early_stopping=False, no_repeat_ngram_size=0, min_length=0, forced_eos_token_id=None, norm="v4.18"):
+    """GenerationMixin.beam_search + BeamSearchScorer.process/finalize of transformers 4.18, driven by a callback
+    `step_logprobs_fn(seqs) -> [B*num_beams, V]` log-softmax of the next-token logits for the current beams."""
+    seqs = [[start] for _ in range(B * num_beams)]
+    beam_scores = torch.zeros(B, num_beams, dtype=torch.float32)
+    beam_scores[:, 1:] = -1e9
+    beam_scores = beam_scores.view(-1)
+    hyps = [_BeamHyps(num_beams, length_penalty, early_stopping, norm) for _ in range(B)]
+    done = [False] * B
+    cur_len = 1
+    while True:
+        lp = step_logprobs_fn(seqs).clone()                              # [B*nb, V] log_softmax
+        V = lp.shape[-1]
+        for r, s in enumerate(seqs):                                     # logits processors, HF order
+            for tok in banned_ngram_tokens(s, no_repeat_ngram_size):
+                lp[r, tok] = -float("inf")
+            if cur_len < min_length:
+                lp[r, eos] = -float("inf")
+            if forced_eos_token_id is not None and cur_len == max_length - 1:
+                keep = lp[r, forced_eos_token_id].clone()
+                lp[r] = -float("inf"); lp[r, forced_eos_token_id] = 0.0 if keep == keep else 0.0
+        scores = (lp + beam_scores[:, None]).view(B, num_beams * V)
+        top_s, top_i = torch.topk(scores, 2 * num_beams, dim=1, largest=True, sorted=True)
+        next_idx = torch.div(top_i, V, rounding_mode="floor"); next_tok = top_i % V
+        new_seqs, new_scores = [], []
+        for b in range(B):
+            if done[b]:
+                new_seqs += [[pad] * 0 + seqs[b * num_beams] + [pad]] * num_beams
+                new_scores += [0.0] * num_beams
+                continue
+            chosen = []
+            for rank in range(2 * num_beams):
+                tok, sc, bi = int(next_tok[b, rank]), float(top_s[b, rank]), int(next_idx[b, rank])
+                src = b * num_beams + bi
+                if tok == eos:
+                    if rank >= num_beams:
+                        continue
+                    hyps[b].add(seqs[src], sc)
+                else:
+                    chosen.append((sc, tok, src))
+                if len(chosen) == num_beams:
+                    break
+            done[b] = done[b] or hyps[b].is_done(float(top_s[b].max()), cur_len)
+            for sc, tok, src in chosen:
+                new_seqs.append(seqs[src] + [tok]); new_scores.append(sc)
+        seqs = new_seqs
+        beam_scores = torch.tensor(new_scores, dtype=torch.float32)
+        cur_len += 1
+        if all(done) or cur_len >= max_length:
+            break
+    out = []
+    for b in range(B):                                                   # finalize
+        if not done[b]:
+            for j in range(num_beams):
+                hyps[b].add(seqs[b * num_beams + j], float(beam_scores[b * num_beams + j]))
+        best = sorted(hyps[b].beams, key=lambda x: x[0])[-1][1]
+        out.append(best)
+    L = min(max(len(o) for o in out) + 1, max_length)
+    res = torch.full((B, L), pad, dtype=torch.long)
+    for b, o in enumerate(out):
+        res[b, :len(o)] = torch.tensor(o)
+        if len(o) < L:
+            res[b, len(o)] = eos
+    return res
+
+
+def beam_search_decode(sd, cfg, input_ids, attention_mask, image_features, num_beams, max_length, length_penalty=1.0, **kw):
+    """Cache-less beam search over the oracle model (config 5: beam 5, max_length 50, length_penalty 2.0)."""
+    gen = {k: kw.pop(k) for k in ("early_stopping", "no_repeat_ngram_size", "min_length", "forced_eos_token_id", "norm") if k in kw}
+    B = input_ids.shape[0]
+    enc_h, _, _, _ = encoder(sd, cfg, input_ids, attention_mask, image_features, kw.get("name_ids"), kw.get("name_mask"),
+                             kw.get("face_features"), kw.get("face_mask"))
+    enc_b = enc_h.repeat_interleave(num_beams, dim=0)
+    mask_b = attention_mask.repeat_interleave(num_beams, dim=0)
+
+    def step(seqs):
+        ids = torch.tensor(seqs, dtype=torch.long)
+        h = decoder(sd, cfg, ids, enc_b, mask_b)[-1][:, -1]
+        return torch.log_softmax(Fn.linear(h, sd["model.shared.weight"]), dim=-1)
+
+    with torch.no_grad():
+        return beam_search_bookkeeping(step, B, num_beams, max_length, cfg.eos_token_id, cfg.pad_token_id,
+                                       cfg.decoder_start_token_id, length_penalty, **gen)

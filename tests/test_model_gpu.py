@@ -218,3 +218,65 @@ def test_greedy_decode_ids_match_oracle():
     mask, _ = K.prep_ids(src.cuda(), 1)
     got = model.greedy_generate(src.cuda(), mask, 8, image_features=img_cls.cuda())
     assert torch.equal(got.cpu(), want), (got.cpu(), want)
+
+
+GEN_CASES = [(5, 2.0, {}), (5, 1.0, {}), (1, 1.0, dict(min_length=4)), (5, 1.0, dict(min_length=4)),
+             (4, 2.0, dict(min_length=3, no_repeat_ngram_size=2)), (3, 0.5, dict(min_length=5, no_repeat_ngram_size=3, early_stopping=True))]
+
+
+def test_beam_search_kv_cache_matches_oracle_and_reference_golden():
+    """config 5 path: KV-cached beam search on the GPU vs the oracle's cache-less restatement (4.18 semantics) and vs the
+    transformers-5.15-over-reference golden (identical sequences on these cases under either length normalisation)."""
+    from oracle import vacnic_oracle as O
+    from vacnic_amd import kernels as K, synthetic
+    from vacnic_amd.config import ClipVisionConfig
+    from vacnic_amd.training import build_models
+    gold = np.load(os.path.join(G, "generate_small.npz"))
+    cfg = small_cfg(encoder_layers=1, decoder_layers=1)
+    model, _, _ = build_models(cfg, ClipVisionConfig(width=128, layers=1, patch_size=16, image_size=32, output_dim=64), init="synthetic")
+    sd = synthetic.make_state_dict(synthetic.mmbart_param_shapes(cfg), seed=1)
+    batch = synthetic.make_batch(cfg, 2, S=24, T=8, F=2, seed=9, image_size=32)
+    img = synthetic._normal("img_cls", (2, 768), 1.0, 3)
+    src = batch["article_ids"]; omask = O.create_src_mask_bart(src)
+    okw = dict(face_features=batch["face_emb"], face_mask=O.create_src_mask_bart(batch["face_emb"][:, :, -1]),
+               name_ids=batch["names_art_ids"], name_mask=O.create_src_mask_bart(batch["names_art_ids"]))
+    dev = {k: v.cuda() for k, v in batch.items()}
+    mask, _ = K.prep_ids(dev["article_ids"], 1)
+    nmask, _ = K.prep_ids(dev["names_art_ids"], 1)
+    for i, (nb, lp, extra) in enumerate(GEN_CASES):
+        got = model.generate(input_ids=dev["article_ids"], attention_mask=mask, num_beams=nb, max_length=12, length_penalty=lp,
+                             image_features=img.cuda(), face_features=dev["face_emb"], face_mask=K.face_mask(dev["face_emb"]),
+                             name_ids=dev["names_art_ids"], name_mask=nmask, add_ner_ffn=True, **extra)
+        want = O.beam_search_decode(sd, cfg, src, omask, img, nb, 12, lp, forced_eos_token_id=2, **extra, **okw)
+        assert torch.equal(got.cpu(), want), (i, got.tolist(), want.tolist())
+        assert np.array_equal(got.cpu().numpy(), gold[f"seq{i}"]), (i, got.tolist(), gold[f"seq{i}"].tolist())
+    # longer greedy run: the KV-cached decoder against the oracle's cache-less decoder
+    a = model.generate(input_ids=dev["article_ids"], attention_mask=mask, num_beams=1, max_length=20, min_length=19,
+                       image_features=img.cuda(), face_features=dev["face_emb"], face_mask=K.face_mask(dev["face_emb"]),
+                       name_ids=dev["names_art_ids"], name_mask=nmask)
+    want = O.beam_search_decode(sd, cfg, src, omask, img, 1, 20, 1.0, forced_eos_token_id=2, min_length=19, **okw)
+    assert torch.equal(a.cpu(), want), (a.tolist(), want.tolist())
+
+
+def test_beam_topk_kernel_matches_torch():
+    from vacnic_amd import kernels as K
+    V, ld, R, Kc = 50267, 50272, 6, 10
+    g = torch.Generator().manual_seed(0)
+    logits = torch.zeros(R, ld); logits[:, :V] = torch.randn(R, V, generator=g) * 3; logits[:, V:] = 1e4
+    bs = torch.randn(R, generator=g)
+    bans = torch.tensor([[5, 7, -1], [-1, -1, -1], [100, 100, 9], [3, -1, -1], [-1, -1, -1], [0, 1, 2]], dtype=torch.int32)
+    lp = torch.log_softmax(logits[:, :V], -1)
+    for r in range(R):
+        for tkn in bans[r].tolist():
+            if tkn >= 0:
+                lp[r, tkn] = -float("inf")
+    lp[:, 2] = -float("inf")
+    want_v, want_i = torch.topk(lp + bs[:, None], Kc, dim=1)
+    tv, ti = K.beam_topk(logits.cuda(), V, Kc, beam_scores=bs.cuda(), bans=bans.cuda(), eos=2, suppress_eos=True)
+    assert torch.equal(ti.cpu().long(), want_i) and torch.allclose(tv.cpu(), want_v, atol=1e-4)
+    tv, ti = K.beam_topk(logits.cuda().bfloat16(), V, 4, beam_scores=bs.cuda(), forced_token=2)
+    assert (ti[:, 0] == 2).all() and torch.allclose(tv[:, 0].cpu(), bs, atol=1e-6) and (tv[:, 1:] == -float("inf")).all()
+    src = torch.arange(6 * 64, dtype=torch.float32).view(6, 64).cuda(); dst = torch.empty_like(src)
+    idx = torch.tensor([5, 0, 0, 3, 2, 1]).cuda()
+    K.gather_rows(src, dst, idx, 6, 64 * 4)
+    assert torch.equal(dst, src[idx])

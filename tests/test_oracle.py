@@ -151,3 +151,28 @@ def test_oracle_greedy_decode_consistent_with_teacher_forcing():
     ids = O.greedy_decode(sd, cfg, src, mask, img_cls, max_length=6)
     out = O.mmbart_forward(sd, cfg, src, mask, ids[:, :-1], img_cls)
     assert torch.equal(out["logits"].argmax(-1), ids[:, 1:])
+
+
+GEN_CASES = [(5, 2.0, {}), (5, 1.0, {}), (1, 1.0, dict(min_length=4)), (5, 1.0, dict(min_length=4)),
+             (4, 2.0, dict(min_length=3, no_repeat_ngram_size=2)), (3, 0.5, dict(min_length=5, no_repeat_ngram_size=3, early_stopping=True))]
+
+
+def gen_inputs():
+    cfg = small_cfg(encoder_layers=1, decoder_layers=1)
+    sd = synthetic.make_state_dict(synthetic.mmbart_param_shapes(cfg), seed=1)
+    batch = synthetic.make_batch(cfg, 2, S=24, T=8, F=2, seed=9, image_size=32)
+    img = synthetic._normal("img_cls", (2, 768), 1.0, 3)
+    kw = dict(face_features=batch["face_emb"], face_mask=O.create_src_mask_bart(batch["face_emb"][:, :, -1]),
+              name_ids=batch["names_art_ids"], name_mask=O.create_src_mask_bart(batch["names_art_ids"]))
+    return cfg, sd, batch, img, kw
+
+
+def test_oracle_beam_search_matches_hf_generate_over_reference_logits():
+    """tests/golden/generate_small.npz = transformers-5.15 GenerationMixin beam search driving the REAL reference model;
+    the oracle restates the 4.18 bookkeeping (norm="v5" selects the newer length normalisation used by that run)."""
+    g = np.load(os.path.join(G, "generate_small.npz"))
+    cfg, sd, batch, img, kw = gen_inputs()
+    src = batch["article_ids"]; mask = O.create_src_mask_bart(src)
+    for i, (nb, lp, extra) in enumerate(GEN_CASES):
+        got = O.beam_search_decode(sd, cfg, src, mask, img, nb, 12, lp, forced_eos_token_id=2, norm="v5", **extra, **kw)
+        assert np.array_equal(got.numpy(), g[f"seq{i}"]), (i, got.tolist(), g[f"seq{i}"].tolist())

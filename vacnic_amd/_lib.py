@@ -133,6 +133,8 @@ _PLAIN_FNS = {
     "vacnic_bias_grad": [vp, vp, i64, i64, i64, vp],
     "vacnic_add_bf16": [vp, vp, vp, i64, vp],
     "vacnic_probe_layouts": [vp, vp, i64, vp],
+    "vacnic_beam_topk": [vp, vp, vp, i32, i32, i32, i32, vp, vp, i64, i64, i64, i32, i32, vp],
+    "vacnic_gather_rows": [vp, vp, vp, i64, i64, vp],
 }
 EXPORTED = sorted(list(_STRUCT_FNS) + list(_PLAIN_FNS) + ["vacnic_last_error_string", "vacnic_version"])
 

@@ -1,0 +1,219 @@
+"""Caption generation on gfx950 kernels: encoder once, then a KV-cached single-token decoder loop with beam
+search — the `model.generate(input_ids, attention_mask, num_beams=5, max_length=50, image_features=..., face_features=...,
+name_ids=..., add_ner_ffn=True[, length_penalty=2.0])` call of TRAIN:513-520 / DDPINF:758-842.
+
+What runs where
+  * device (hand-written kernels): embed+pos+LN of the new token, fused k|v|q projection, KV-cache append, fused
+    attention over the cache (self) and over the per-layer cross K/V computed once from the encoder states, FFN,
+    LM head, log-softmax + logits processors + top-2k (`beam_topk`), cache reorder for all layers in one launch
+    (`gather_rows`; _reorder_cache MFULL:2066-2074 — cross K/V are never reordered, as in the reference).
+  * host: the n-best bookkeeping of transformers 4.18 BeamSearchScorer (a few dozen scalars per step).  This costs one
+    device->host copy of [B*beams, 2*beams] candidates per token; moving it on device is the "next" item of SURVEY §8f-1.
+
+The cache is preallocated ([layers, B*beams, max_length, 2d] bf16, k|v interleaved per row) instead of the reference's
+per-step torch.cat (MFULL:489-492).
+"""
+import torch
+
+from . import kernels as K
+
+BF16 = torch.bfloat16
+
+
+class _BeamHyps:
+    """n-best list of finished hypotheses, scored sum_logprobs / len**length_penalty (len counts the decoder start token,
+    not the closing EOS) — transformers==4.18 BeamHypotheses."""
+
+    def __init__(self, n, length_penalty, early_stopping):
+        self.n, self.lp, self.early = n, length_penalty, early_stopping
+        self.beams, self.worst = [], 1e9
+
+    def add(self, hyp, sum_logprobs):
+        score = sum_logprobs / (len(hyp) ** self.lp)
+        if len(self.beams) < self.n or score > self.worst:
+            self.beams.append((score, list(hyp)))
+            if len(self.beams) > self.n:
+                srt = sorted((s, i) for i, (s, _) in enumerate(self.beams))
+                del self.beams[srt[0][1]]
+                self.worst = srt[1][0]
+            else:
+                self.worst = min(score, self.worst)
+
+    def is_done(self, best_sum_logprobs, cur_len):
+        if len(self.beams) < self.n:
+            return False
+        if self.early:
+            return True
+        return self.worst >= best_sum_logprobs / cur_len ** self.lp
+
+
+def _banned(seq, n):
+    if n <= 0 or len(seq) + 1 < n:
+        return []
+    prefix = tuple(seq[len(seq) - (n - 1):]) if n > 1 else ()
+    return [seq[i + n - 1] for i in range(len(seq) - n + 1) if tuple(seq[i:i + n - 1]) == prefix]
+
+
+class CachedDecoder:
+    """Single-token decoder over preallocated KV caches (eval mode, no autograd)."""
+
+    def __init__(self, model, enc_h, enc_mask_u8, rows, max_length):
+        self.m = model
+        dec = model.model.decoder
+        self.dec = dec
+        self.L = len(dec.layers)
+        d = model.config.d_model
+        self.d, self.H = d, model.config.decoder_attention_heads
+        self.rows, self.Tmax = rows, max_length
+        dev = enc_h.device
+        self.cache = [torch.zeros((self.L, rows, max_length, 2 * d), device=dev, dtype=BF16) for _ in range(2)]
+        self.cur = 0
+        self.enc_mask = enc_mask_u8
+        S = enc_h.shape[1]
+        M = rows * S
+        # cross-attention K/V of every layer, once (the decoder's largest GEMMs: M = rows*S)
+        self.cross = []
+        for layer in dec.layers:
+            a = layer.encoder_attn
+            self.cross.append(K.gemm(enc_h.view(M, d), a.s_kv.w16, M, 2 * d, d, bias=a.s_kv.bias).view(rows, S, 2 * d))
+
+    def step(self, ids_t, t):
+        """ids_t int64 [rows, 1] (token at position t) -> fp32 logits [rows, V_pad]."""
+        m, dec, d, H, R = self.m, self.dec, self.d, self.H, self.rows
+        ln = dec.layernorm_embedding
+        h, _, _ = K.embed_ln_fwd(ids_t, dec.embed_tokens.weight.w16, dec.embed_positions.weight.w16, ln.weight.data, ln.bias.data,
+                                 embed_scale=dec.embed_scale, pos_offset=2 + t)
+        cache = self.cache[self.cur]
+        for li, layer in enumerate(dec.layers):
+            a = layer.self_attn
+            kvq = K.gemm(h.view(R, d), a.s_kvq.w16, R, 3 * d, d, bias=a.s_kvq.bias).view(R, 1, 3 * d)
+            K.copy3d(kvq[..., :2 * d], cache[li][:, t:t + 1], R, 1, 2 * d)                      # append k|v (MFULL:489-492)
+            ctx, _ = K.attn_fwd(kvq[..., 2 * d:], cache[li][:, :t + 1, :d], cache[li][:, :t + 1, d:], R, H, 1, t + 1, need_lse=False)
+            o = K.gemm(ctx.view(R, d), a.s_out.w16, R, d, d, bias=a.s_out.bias)
+            h, _, _ = K.add_ln_fwd(o.view(R, 1, d), h, layer.self_attn_layer_norm.weight.data, layer.self_attn_layer_norm.bias.data,
+                                   need_stats=False)
+            c = layer.encoder_attn
+            q = K.gemm(h.view(R, d), c.s_q.w16, R, d, d, bias=c.s_q.bias).view(R, 1, d)
+            kv = self.cross[li]
+            ctx, _ = K.attn_fwd(q, kv[..., :d], kv[..., d:], R, H, 1, kv.shape[1], key_mask=self.enc_mask, need_lse=False)
+            o = K.gemm(ctx.view(R, d), c.s_out.w16, R, d, d, bias=c.s_out.bias)
+            h, _, _ = K.add_ln_fwd(o.view(R, 1, d), h, layer.encoder_attn_layer_norm.weight.data, layer.encoder_attn_layer_norm.bias.data,
+                                   need_stats=False)
+            f = K.gemm(h.view(R, d), layer.s_fc1.w16, R, layer.s_fc1.N, d, bias=layer.s_fc1.bias, act="gelu")
+            o = K.gemm(f, layer.s_fc2.w16, R, d, layer.s_fc2.K, bias=layer.s_fc2.bias)
+            h, _, _ = K.add_ln_fwd(o.view(R, 1, d), h, layer.final_layer_norm.weight.data, layer.final_layer_norm.bias.data, need_stats=False)
+        logits = torch.empty((R, m.V_pad), device=h.device, dtype=torch.float32)
+        K.gemm(h.view(R, d), m.emb16_pad, R, m.V, d, bias=m.final_logits_bias.view(-1), out=logits, ldo=m.V_pad, out_mode=1)
+        return logits
+
+    def reorder(self, beam_idx):
+        """self-attention caches of all layers follow their beams (one launch)."""
+        L, R = self.L, self.rows
+        idx = (torch.arange(L, device=beam_idx.device)[:, None] * R + beam_idx[None, :]).reshape(-1).contiguous()
+        src, dst = self.cache[self.cur], self.cache[self.cur ^ 1]
+        K.gather_rows(src, dst, idx, L * R, self.Tmax * 2 * self.d * 2)
+        self.cur ^= 1
+
+
+@torch.no_grad()
+def generate(model, input_ids=None, attention_mask=None, num_beams=1, max_length=20, length_penalty=1.0, early_stopping=False,
+             no_repeat_ngram_size=0, min_length=0, forced_eos_token_id="config", image_features=None, face_features=None,
+             face_mask=None, name_ids=None, name_mask=None, add_ner_ffn=True, **unused):
+    """GenerationMixin.generate(do_sample=False) semantics of transformers 4.18 for this model (greedy = 1 beam).
+    Returns int64 [B, L] starting with decoder_start_token_id, padded with pad_token_id."""
+    cfg = model.config
+    if model.arena is None:
+        raise RuntimeError("call model.finalize(device) first")
+    was_training = model.training
+    model.eval()
+    eos, pad, start = cfg.eos_token_id, cfg.pad_token_id, cfg.decoder_start_token_id
+    if forced_eos_token_id == "config":
+        forced_eos_token_id = eos                     # BartConfig default forced_eos_token_id=2
+    B = input_ids.shape[0]
+    nb = num_beams
+    R = B * nb
+    mask_u8 = attention_mask.to(torch.uint8) if attention_mask.dtype != torch.uint8 else attention_mask
+    enc = model.model.encoder(input_ids=input_ids, attention_mask=mask_u8, image_features=image_features, name_ids=name_ids,
+                              name_mask=name_mask, face_features=face_features, face_mask=face_mask, add_ner_ffn=add_ner_ffn)
+    enc_h = enc["last_hidden_state"]
+    S, d = enc_h.shape[1], enc_h.shape[2]
+    # expand to beams (HF _expand_inputs_for_generation): row b*nb + j <- batch b
+    enc_b = torch.empty((R, S, d), device=enc_h.device, dtype=BF16)
+    mask_b = mask_u8.repeat_interleave(nb, dim=0).contiguous()
+    for j in range(nb):
+        K.copy3d(enc_h, enc_b[j::nb], B, S, d)
+    dec = CachedDecoder(model, enc_b, mask_b, R, max_length)
+
+    seqs = [[start] for _ in range(R)]
+    beam_scores = torch.zeros((B, nb), dtype=torch.float32)
+    beam_scores[:, 1:] = -1e9
+    beam_scores = beam_scores.view(-1)
+    hyps = [_BeamHyps(nb, length_penalty, early_stopping) for _ in range(B)]
+    done = [False] * B
+    cur_len = 1
+    Kc = 2 * nb
+    dev = enc_h.device
+    while True:
+        t = cur_len - 1
+        ids_t = torch.tensor([[s[-1]] for s in seqs], dtype=torch.long, device=dev)
+        logits = dec.step(ids_t, t)
+        bans = None
+        if no_repeat_ngram_size > 0:
+            bl = [_banned(s, no_repeat_ngram_size) for s in seqs]
+            width = max(1, max(len(b) for b in bl))
+            bans = torch.tensor([b + [-1] * (width - len(b)) for b in bl], dtype=torch.int32, device=dev)
+        forced = forced_eos_token_id if (forced_eos_token_id is not None and cur_len == max_length - 1) else -1
+        tv, ti = K.beam_topk(logits, model.V, min(Kc, model.V), beam_scores=beam_scores.to(dev), bans=bans, eos=eos,
+                             suppress_eos=cur_len < min_length, forced_token=forced)
+        tv, ti = tv.cpu(), ti.cpu()                                   # the one device->host sync of the step
+        new_seqs, new_scores, new_src = [], [], []
+        for b in range(B):
+            if done[b]:
+                new_seqs += [seqs[b * nb] + [pad]] * nb; new_scores += [0.0] * nb; new_src += [b * nb] * nb
+                continue
+            # merge the per-beam top-2k lists into the group's top-2k (HF: topk over the [nb*V] scores of the group)
+            cand = []
+            for j in range(nb):
+                for c in range(tv.shape[1]):
+                    if ti[b * nb + j, c] >= 0:
+                        cand.append((float(tv[b * nb + j, c]), j, int(ti[b * nb + j, c])))
+            cand.sort(key=lambda x: (-x[0], x[1] * model.V + x[2]))
+            cand = cand[:Kc]
+            chosen = []
+            for rank, (sc, j, tok) in enumerate(cand):
+                src = b * nb + j
+                if tok == eos:
+                    if rank >= nb:
+                        continue
+                    hyps[b].add(seqs[src], sc)
+                else:
+                    chosen.append((sc, tok, src))
+                if len(chosen) == nb:
+                    break
+            done[b] = done[b] or hyps[b].is_done(cand[0][0], cur_len)
+            while len(chosen) < nb:                                     # cannot happen with 2*nb candidates; keep shapes sane
+                chosen.append((-1e9, pad, b * nb))
+            for sc, tok, src in chosen:
+                new_seqs.append(seqs[src] + [tok]); new_scores.append(sc); new_src.append(src)
+        seqs = new_seqs
+        beam_scores = torch.tensor(new_scores, dtype=torch.float32)
+        cur_len += 1
+        if all(done) or cur_len >= max_length:
+            break
+        if nb > 1:
+            dec.reorder(torch.tensor(new_src, dtype=torch.long, device=dev))
+    out = []
+    for b in range(B):
+        if not done[b]:
+            for j in range(nb):
+                hyps[b].add(seqs[b * nb + j], float(beam_scores[b * nb + j]))
+        out.append(sorted(hyps[b].beams, key=lambda x: x[0])[-1][1])
+    L = min(max(len(o) for o in out) + 1, max_length)
+    res = torch.full((B, L), pad, dtype=torch.long)
+    for b, o in enumerate(out):
+        res[b, :len(o)] = torch.tensor(o)
+        if len(o) < L:
+            res[b, len(o)] = eos
+    if was_training:
+        model.train()
+    return res.to(dev)

@@ -316,3 +316,17 @@ def probe_layouts():
     src = torch.arange(128, device="cuda", dtype=torch.float32) + 1.0
     call("vacnic_probe_layouts", _p(out), _p(src), out.numel(), _stream())
     return out
+
+
+# ------------------------------------------------------------------------------------------------ decode
+def beam_topk(logits, V, K_, beam_scores=None, bans=None, eos=2, suppress_eos=False, forced_token=-1):
+    R = logits.shape[0]
+    tv = torch.empty((R, K_), device=logits.device, dtype=torch.float32)
+    ti = torch.empty((R, K_), device=logits.device, dtype=torch.int32)
+    call("vacnic_beam_topk", _p(logits), _p(beam_scores), _p(bans), bans.shape[1] if bans is not None else 0, eos, int(suppress_eos),
+         forced_token, _p(tv), _p(ti), R, V, logits.stride(0), K_, int(logits.dtype == torch.float32), _stream())
+    return tv, ti
+
+
+def gather_rows(src, dst, idx, rows, row_bytes):
+    call("vacnic_gather_rows", _p(src), _p(dst), _p(idx), rows, row_bytes, _stream())

@@ -464,7 +464,18 @@ class BartForMultiModalGeneration(nn.Module):
             out["logits"] = lg
         return out
 
-    # ---- decoding (TRAIN:480-559 calls model.generate; greedy here, beam search in vacnic_amd.generate) ----
+    # ---- decoding (TRAIN:480-559, DDPINF:758-842 call model.generate) ----
+    def generate(self, input_ids=None, attention_mask=None, **kw):
+        """KV-cached greedy / beam search with transformers-4.18 semantics: see vacnic_amd/generate.py."""
+        from ..generate import generate as _generate
+        return _generate(self, input_ids=input_ids, attention_mask=attention_mask, **kw)
+
+    def prepare_inputs_for_generation(self, decoder_input_ids, past=None, **kw):
+        """MFULL:2023-2061 contract: with a cache only the last token is fed (the cached decoder does exactly that)."""
+        if past is not None:
+            decoder_input_ids = decoder_input_ids[:, -1:]
+        return dict(kw, decoder_input_ids=decoder_input_ids, past_key_values=past)
+
     @torch.no_grad()
     def greedy_generate(self, input_ids, attention_mask, max_length, **kw):
         enc = self.model.encoder(input_ids=input_ids, attention_mask=attention_mask, **kw)
