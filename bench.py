@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--cap", type=int, default=64, help="caption tokens T")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=1)
+    ap.add_argument("--no-streams", action="store_true", help="single-stream schedule (no side streams for guide / wgrad)")
     return ap.parse_args()
 
 
@@ -158,6 +159,8 @@ def main():
     from vacnic_amd.ddp import DistributedDataParallel
     from vacnic_amd.training import FusedAdamW, TrainArgs, build_models, to_device, train_step
 
+    from vacnic_amd import streams
+    streams.enable(not a.no_streams)
     cfg, vcfg = bart_large_vit_l14()
     B, S, T = a.batch, a.seq, a.cap
     log("building models (random init on device)")

@@ -40,10 +40,12 @@ def slices(t, n=4096):
     return f[::step][:n].float().numpy()
 
 
+@pytest.mark.parametrize("side_streams", [False, True])
 @pytest.mark.parametrize("case", list(CASES))
-def test_full_model_matches_oracle_and_reference_golden(case):
+def test_full_model_matches_oracle_and_reference_golden(case, side_streams):
     from oracle import vacnic_oracle as O
-    from vacnic_amd import kernels as K, ops, synthetic
+    from vacnic_amd import kernels as K, ops, streams, synthetic
+    streams.enable(side_streams)            # weight gradients on the side stream must give the same numbers
     from vacnic_amd.config import ClipVisionConfig
     from vacnic_amd.training import TrainArgs, build_models
     ckw, dims = CASES[case]
@@ -104,6 +106,9 @@ def test_full_model_matches_oracle_and_reference_golden(case):
     assert abs(oloss.item() - float(gold["loss"])) < 1e-4 * float(gold["loss"])
     oloss.backward()
     total.backward()
+    streams.join_all()
+    torch.cuda.synchronize()
+    streams.enable(False)
     worst = []
     for name, p in model.named_parameters():
         if name.startswith("clip_model") or name == "lm_head.weight" or name.endswith("embed_tokens.weight"):
@@ -187,11 +192,14 @@ def test_train_steps_reduce_loss_and_match_oracle_adamw():
     args = TrainArgs(num_training_steps=20, warmup_rate=0.1, lr_bart=1e-4)
     opt = FusedAdamW(model.arena, lr=args.lr_bart, weight_decay=args.weight_decay, num_warmup_steps=2, num_training_steps=20)
     batch = to_device(synthetic.make_batch(cfg, 4, S=32, T=12, F=3, seed=11, image_size=32), "cuda")
+    from vacnic_amd import streams
+    streams.enable(True)                    # guide forward on the aux stream, weight gradients on the wgrad stream
     p0 = model.arena.flat32.clone()
     losses = []
     for step in range(6):
         out4 = train_step(model, guide, opt, batch, args)
         losses.append(out4.tolist())
+    streams.enable(False)
     assert all(np.isfinite(l).all() for l in losses)
     assert losses[-1][1] < losses[0][1], f"text loss should fall on a repeated batch: {losses[0][1]} -> {losses[-1][1]}"
     assert (model.arena.grad == 0).all(), "AdamW clears the gradient arena"

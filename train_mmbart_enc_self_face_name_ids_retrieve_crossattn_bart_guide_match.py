@@ -85,7 +85,7 @@ CLIP = {"ViT-B/32": dict(width=768, layers=12, patch_size=32, output_dim=512), "
 def run(args, batches=None):
     import torch
     import torch.distributed as dist
-    from vacnic_amd import ops, synthetic
+    from vacnic_amd import ops, streams, synthetic
     from vacnic_amd.config import ClipVisionConfig, VacnicConfig
     from vacnic_amd.ddp import DistributedDataParallel
     from vacnic_amd.training import FusedAdamW, TrainArgs, build_models, to_device, train_step
@@ -99,6 +99,7 @@ def run(args, batches=None):
     if world > 1:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
     ops.Rng.manual_seed(int(args.seed) + rank)
+    streams.enable(True)                     # guide forward + weight gradients on side streams
     vkw = CLIP[args.clip_type]
     cfg = VacnicConfig(enc_fusion_layer=list(args.enc_fusion_layer or []), dim_common=args.dim_common, prompt_size=args.prompt_size,
                        max_ner_type_len=args.max_ner_type_len, max_ner_type_len_gt=args.max_ner_type_len_gt,

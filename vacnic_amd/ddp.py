@@ -112,10 +112,14 @@ class DistributedDataParallel(torch.nn.Module):
         self.launched.add(start)
         g = self.arena.grad[start:self.bucket_end[start]]
         if self.comm_stream is not None:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
+            # the bucket's writers may sit on the compute stream (LN / embedding grads) and on the weight-gradient
+            # side stream (wgrad GEMMs): the collective waits for both
+            from . import streams
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            for s in (streams.wgrad_stream(), torch.cuda.default_stream()):
+                if s is not None:
+                    self.comm_stream.wait_stream(s)
             with torch.cuda.stream(self.comm_stream):
-                self.comm_stream.wait_event(ev)
                 self.works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
         else:
             self.works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))

@@ -16,6 +16,7 @@ from torch.autograd import Function
 
 from . import ddp
 from . import kernels as K
+from . import streams
 
 BF16 = torch.bfloat16
 
@@ -52,9 +53,19 @@ def _c(t):
 
 
 def _wgrad(dy2d, x2d, spec, M):
-    """spec.wgrad[N,K] += dy^T x ; spec.bgrad[N] += colsum(dy)."""
-    _wgrad_impl(dy2d, x2d, spec, M)
-    ddp.done(spec.wgrad, spec.bgrad)
+    """spec.wgrad[N,K] += dy^T x ; spec.bgrad[N] += colsum(dy).  Off the critical path: issued on the weight-gradient
+    side stream when streams are enabled (each weight has exactly one writer op, so there is no cross-stream race)."""
+    side = streams.wgrad_stream()
+    if side is None:
+        _wgrad_impl(dy2d, x2d, spec, M)
+        ddp.done(spec.wgrad, spec.bgrad)
+        return
+    side.wait_stream(torch.cuda.current_stream())          # dy / x were produced on the compute stream
+    with torch.cuda.stream(side):
+        _wgrad_impl(dy2d, x2d, spec, M)
+        ddp.done(spec.wgrad, spec.bgrad)
+    dy2d.record_stream(side)
+    x2d.record_stream(side)
 
 
 def _wgrad_impl(dy2d, x2d, spec, M):

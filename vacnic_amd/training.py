@@ -8,6 +8,7 @@ import torch
 
 from . import kernels as K
 from . import ops
+from . import streams
 from .config import ClipVisionConfig, VacnicConfig
 from .ddp import DistributedDataParallel
 from .models.clip_vit import CLIPVisualOnly, extract_clip_img_feat
@@ -116,6 +117,15 @@ def forward_losses(model, guide, batch, args: TrainArgs):
     src, tgt = batch["article_ids"], batch["caption_ids"]
     src_mask, _ = K.prep_ids(src, cfg.pad_token_id)                                          # create_src_mask_bart, TRAIN:268
     tgt_mask, tgt_in = K.prep_ids(tgt, cfg.pad_token_id, start_id=cfg.eos_token_id)         # shift_tokens_right, TRAIN:267,296
+    # the frozen guide forward is independent of the student until the CoLaM loss: issue it on the aux stream, ahead of
+    # the ViT, so its kernels fill the bubbles of the main chain
+    aux = streams.aux_stream() if guide is not None else None
+    if aux is not None:
+        aux.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(aux):
+            gh = guide(input_ids=src, attention_mask=src_mask, decoder_input_ids=tgt_in)["decoder_hidden_states"][-1]   # TRAIN:293-294
+        for tns in (src, src_mask, tgt_in):
+            tns.record_stream(aux)
     _, img_cls = extract_clip_img_feat(net.clip_model, batch["img_tensor"])                   # TRAIN:274-276
     kw = {}
     if not cfg.only_image:
@@ -127,7 +137,11 @@ def forward_losses(model, guide, batch, args: TrainArgs):
     txt = out["loss"]
     colam = secla = None
     if guide is not None:
-        gh = guide(input_ids=src, attention_mask=src_mask, decoder_input_ids=tgt_in)["decoder_hidden_states"][-1]   # TRAIN:293-294
+        if aux is not None:
+            torch.cuda.current_stream().wait_stream(aux)
+            gh.record_stream(torch.cuda.current_stream())
+        else:
+            gh = guide(input_ids=src, attention_mask=src_mask, decoder_input_ids=tgt_in)["decoder_hidden_states"][-1]   # TRAIN:293-294
         colam = ops.ColamFn.apply(out["decoder_hidden_states"][-1], gh, tgt_mask, args.margin, args.alpha)        # TRAIN:296-307
     if args.use_secla and not args.no_mapping and not cfg.only_image:
         enc = net.model.encoder
@@ -146,6 +160,7 @@ def train_step(model, guide, optimizer, batch, args: TrainArgs):
     net.train()
     total, out4, _ = forward_losses(model, guide, batch, args)
     total.backward()
+    streams.join_all()                       # weight-gradient side stream -> compute stream
     if isinstance(model, DistributedDataParallel):
         model.reduce_gradients()
     if not args.no_clip_norm:
