@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=1)
     ap.add_argument("--no-streams", action="store_true", help="single-stream schedule (no side streams for guide / wgrad)")
+    ap.add_argument("--graph", action="store_true", help="replay the step as one captured hipGraph (world 1 only). Measured slower than "
+                    "eager multi-stream launches while the step is GPU-bound (91.0 vs 86.2 ms: hipGraph runs the side-stream branches "
+                    "less concurrently), so eager is the default")
     return ap.parse_args()
 
 
@@ -157,7 +160,7 @@ def main():
     from vacnic_amd import synthetic
     from vacnic_amd.config import bart_large_vit_l14
     from vacnic_amd.ddp import DistributedDataParallel
-    from vacnic_amd.training import FusedAdamW, TrainArgs, build_models, to_device, train_step
+    from vacnic_amd.training import FusedAdamW, GraphedTrainStep, TrainArgs, build_models, to_device, train_step
 
     from vacnic_amd import streams
     streams.enable(not a.no_streams)
@@ -175,11 +178,24 @@ def main():
     batches = [to_device(synthetic.make_batch(cfg, B, S=S, T=T, seed=42, rank=rank, step=i, full_length=True), "cuda") for i in range(nb)]
     torch.cuda.synchronize()
 
-    log("batches resident; warm-up")
-    for i in range(a.warmup):
-        train_step(net, guide, opt, batches[i % nb], args)
-        torch.cuda.synchronize()
-        log(f"warm-up step {i} done")
+    use_graph = world == 1 and a.graph
+    log(f"batches resident; warm-up ({'hipGraph capture' if use_graph else 'eager'})")
+    graphed = None
+    if use_graph:
+        try:
+            graphed = GraphedTrainStep(net, guide, opt, args, batches[0], warmup=max(1, a.warmup - 1))
+            graphed(batches[1 % nb])
+            torch.cuda.synchronize()
+            log("graph captured and replayed once")
+        except Exception as e:                      # never lose the measurement to a capture problem
+            log(f"graph capture failed ({e!r}); falling back to eager launches")
+            graphed = None
+            torch.cuda.synchronize()
+    if graphed is None:
+        for i in range(a.warmup):
+            train_step(net, guide, opt, batches[i % nb], args)
+            torch.cuda.synchronize()
+            log(f"warm-up step {i} done")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -187,9 +203,15 @@ def main():
     t0 = time.perf_counter()
     out4 = None
     for i in range(a.steps):
+        bt = batches[(a.warmup + i) % nb]
         if i == a.steps - 1:
+            # last timed step: eager, with HIP events around every GEMM launch (roofline of the dominant kernel)
             timer.install()
-        out4 = train_step(net, guide, opt, batches[(a.warmup + i) % nb], args)
+            out4 = train_step(net, guide, opt, bt, args)
+        elif graphed is not None:
+            out4 = graphed(bt)
+        else:
+            out4 = train_step(net, guide, opt, bt, args)
     timer.remove()
     host_dt = time.perf_counter() - t0           # host-side enqueue time of the K steps (GPU may still be running)
     torch.cuda.synchronize()
@@ -237,6 +259,7 @@ def main():
                "config": {"workload": f"BASELINE configs[{1 if world == 1 else 2}]: BART-large + CLIP ViT-L/14 full VACNIC (clipcap P=20, SECLA, CoLaM a=0.5 m=1.0), "
                                       f"224x224 image, {S}-token article, {T}-token caption, per-GPU batch {B}, dropout 0.1, fp32 master + bf16 compute",
                           "global_batch": B * world, "seq_len": S, "caption_len": T, "parallelism": f"dp{world}"},
+               "launch_mode": "hipGraph replay (K-1 steps) + 1 eager instrumented step" if graphed is not None else "eager",
                "host_enqueue_ms_per_step": round(host_dt / a.steps * 1e3, 2),
                "step_tflops_per_gpu": round(value / world * gf / 1e3, 1) if gf else None,
                "step_mfma_frac": round(value / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4) if gf else None,

@@ -115,6 +115,7 @@ typedef struct {
   const void* x; const void* residual; const float* gamma; const float* beta;
   void* out; float* mean; float* rstd;
   int64_t R, D; float eps; float p_drop; uint64_t seed;
+  const uint64_t* seed_dev;      /* optional device counter mixed into the seed (fresh masks under hipGraph replay) */
 } vacnic_add_ln_fwd_args;
 int vacnic_add_ln_fwd(const vacnic_add_ln_fwd_args* a, void* stream);
 
@@ -125,7 +126,7 @@ typedef struct {
   const void* dout; const void* x; const void* residual; const float* gamma;
   const float* mean; const float* rstd;
   void* dresidual; void* dx; float* dgamma; float* dbeta;
-  int64_t R, D; float p_drop; uint64_t seed;
+  int64_t R, D; float p_drop; uint64_t seed; const uint64_t* seed_dev;
 } vacnic_add_ln_bwd_args;
 int vacnic_add_ln_bwd(const vacnic_add_ln_bwd_args* a, void* stream);
 
@@ -138,6 +139,7 @@ typedef struct {
   const int64_t* ids; const void* embed; const void* pos; const float* gamma; const float* beta;
   void* out; float* mean; float* rstd;
   int64_t B, T, D, V; int64_t pos_offset; float embed_scale; float eps; float p_drop; uint64_t seed;
+  const uint64_t* seed_dev;
 } vacnic_embed_ln_fwd_args;
 int vacnic_embed_ln_fwd(const vacnic_embed_ln_fwd_args* a, void* stream);
 
@@ -147,7 +149,7 @@ typedef struct {
   float* dembed; float* dpos; float* dgamma; float* dbeta;   /* f32 accumulate (atomics); any may be NULL */
   int64_t B, T, D, V; int64_t pos_offset; float embed_scale;
   int64_t padding_idx;                        /* rows with ids == padding_idx get no embedding grad (nn.Embedding) */
-  float p_drop; uint64_t seed;
+  float p_drop; uint64_t seed; const uint64_t* seed_dev;
 } vacnic_embed_ln_bwd_args;
 int vacnic_embed_ln_bwd(const vacnic_embed_ln_bwd_args* a, void* stream);
 
@@ -231,8 +233,9 @@ typedef struct {
 } vacnic_adamw_args;
 int vacnic_adamw(const vacnic_adamw_args* a, void* stream);
 /* get_linear_schedule_with_warmup on device (TRAIN:99-107): hyper[0] <- base_lr*lambda(k), hyper[1] <- k+1
- * where k = hyper[1] on entry = optimizer steps already taken.  Call once before vacnic_adamw. */
-int vacnic_lr_step(float* hyper, float base_lr, float warmup_steps, float total_steps, void* stream);
+ * where k = hyper[1] on entry = optimizer steps already taken.  Also increments *rng_counter (the device-side
+ * dropout counter, may be NULL).  Call once before vacnic_adamw. */
+int vacnic_lr_step(float* hyper, float base_lr, float warmup_steps, float total_steps, uint64_t* rng_counter, void* stream);
 
 /* ---- small data-movement helpers on the path ------------------------------------------------- */
 /* f32 -> bf16 cast (weight shadow refresh, inputs). */

@@ -57,23 +57,23 @@ AttnBwdArgs = _struct("vacnic_attn_bwd_args", [
 
 AddLnFwdArgs = _struct("vacnic_add_ln_fwd_args", [
     ("x", vp), ("residual", vp), ("gamma", vp), ("beta", vp), ("out", vp), ("mean", vp), ("rstd", vp),
-    ("R", i64), ("D", i64), ("eps", f32), ("p_drop", f32), ("seed", u64)])
+    ("R", i64), ("D", i64), ("eps", f32), ("p_drop", f32), ("seed", u64), ("seed_dev", vp)])
 
 AddLnBwdArgs = _struct("vacnic_add_ln_bwd_args", [
     ("dout", vp), ("x", vp), ("residual", vp), ("gamma", vp), ("mean", vp), ("rstd", vp),
     ("dresidual", vp), ("dx", vp), ("dgamma", vp), ("dbeta", vp),
-    ("R", i64), ("D", i64), ("p_drop", f32), ("seed", u64)])
+    ("R", i64), ("D", i64), ("p_drop", f32), ("seed", u64), ("seed_dev", vp)])
 
 EmbedLnFwdArgs = _struct("vacnic_embed_ln_fwd_args", [
     ("ids", vp), ("embed", vp), ("pos", vp), ("gamma", vp), ("beta", vp), ("out", vp), ("mean", vp), ("rstd", vp),
     ("B", i64), ("T", i64), ("D", i64), ("V", i64), ("pos_offset", i64),
-    ("embed_scale", f32), ("eps", f32), ("p_drop", f32), ("seed", u64)])
+    ("embed_scale", f32), ("eps", f32), ("p_drop", f32), ("seed", u64), ("seed_dev", vp)])
 
 EmbedLnBwdArgs = _struct("vacnic_embed_ln_bwd_args", [
     ("ids", vp), ("embed", vp), ("pos", vp), ("dout", vp), ("gamma", vp), ("mean", vp), ("rstd", vp),
     ("dembed", vp), ("dpos", vp), ("dgamma", vp), ("dbeta", vp),
     ("B", i64), ("T", i64), ("D", i64), ("V", i64), ("pos_offset", i64), ("embed_scale", f32),
-    ("padding_idx", i64), ("p_drop", f32), ("seed", u64)])
+    ("padding_idx", i64), ("p_drop", f32), ("seed", u64), ("seed_dev", vp)])
 
 CeArgs = _struct("vacnic_ce_args", [
     ("logits", vp), ("targets", vp), ("row_lse", vp), ("row_loss", vp), ("loss_sum", vp), ("count", vp),
@@ -119,7 +119,7 @@ _STRUCT_FNS = {
 }
 _PLAIN_FNS = {
     "vacnic_combine_losses": [vp, vp, vp, vp, f32, f32, vp, vp],
-    "vacnic_lr_step": [vp, f32, f32, f32, vp],
+    "vacnic_lr_step": [vp, f32, f32, f32, vp, vp],
     "vacnic_cast_f32_bf16": [vp, vp, i64, vp],
     "vacnic_cast_bf16_f32": [vp, vp, i64, vp],
     "vacnic_copy2d_bf16": [vp, vp, i64, i64, i64, i64, i32, vp],

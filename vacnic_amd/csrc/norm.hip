@@ -11,6 +11,12 @@ namespace {
 
 constexpr int ROWS_PER_BLOCK = 4;   // 4 waves
 
+// per-site host seed combined with a per-step counter that lives in device memory, so a captured hipGraph
+// draws fresh dropout masks on every replay (the host seed is frozen into the graph)
+__device__ __forceinline__ uint64_t mix_seed(uint64_t seed, const uint64_t* seed_dev) {
+  return seed_dev ? seed ^ (*seed_dev * 0x9E3779B97F4A7C15ull) : seed;
+}
+
 __device__ __forceinline__ void load8(const bf16_t* p, float v[8]) {
   u32x4 r = *(const u32x4*)p;
 #pragma unroll
@@ -40,10 +46,11 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const bf16_t* __restric
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          bf16_t* __restrict__ out, float* __restrict__ mean_o,
                                                          float* __restrict__ rstd_o, int64_t R, int D, float eps,
-                                                         float p_drop, uint64_t seed) {
+                                                         float p_drop, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= R) return;
+  seed = mix_seed(seed, seed_dev);
   const int nchunk = D >> 3;
   const uint32_t thr = dropout_threshold(p_drop);
   const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
@@ -116,9 +123,10 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const bf16_t* __restric
                                                          const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                          bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
                                                          float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                         int64_t R, int D, float p_drop, uint64_t seed) {
+                                                         int64_t R, int D, float p_drop, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
+  seed = mix_seed(seed, seed_dev);
   const int nchunk = D >> 3;
   const uint32_t thr = dropout_threshold(p_drop);
   const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
@@ -212,10 +220,11 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* __rest
                                                            const float* __restrict__ beta, bf16_t* __restrict__ out,
                                                            float* __restrict__ mean_o, float* __restrict__ rstd_o,
                                                            int64_t R, int T, int D, int64_t V, int pos_offset, float scale,
-                                                           float eps, float p_drop, uint64_t seed) {
+                                                           float eps, float p_drop, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= R) return;
+  seed = mix_seed(seed, seed_dev);
   const int nchunk = D >> 3;
   int64_t id = ids[row];
   id = id < 0 ? 0 : (id >= V ? V - 1 : id);   // clamp: a bad id must not fault the GPU
@@ -274,9 +283,10 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const int64_t* __rest
                                                            float* __restrict__ dpos, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, int64_t R, int T, int D, int64_t V,
                                                            int pos_offset, float scale, int64_t padding_idx, float p_drop,
-                                                           uint64_t seed) {
+                                                           uint64_t seed, const uint64_t* __restrict__ seed_dev) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
+  seed = mix_seed(seed, seed_dev);
   const int nchunk = D >> 3;
   const uint32_t thr = dropout_threshold(p_drop);
   const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
@@ -444,7 +454,7 @@ extern "C" int vacnic_add_ln_fwd(const vacnic_add_ln_fwd_args* a, void* stream) 
   dim3 grid((unsigned)((a->R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
   DISPATCH_NCH(nch_for(a->D), add_ln_fwd_kernel, grid, (hipStream_t)stream, (const bf16_t*)a->x,
                (const bf16_t*)a->residual, a->gamma, a->beta, (bf16_t*)a->out, a->mean, a->rstd, a->R, (int)a->D,
-               a->eps, a->p_drop, a->seed);
+               a->eps, a->p_drop, a->seed, a->seed_dev);
   VLAUNCH_CHECK();
   return VACNIC_OK;
 }
@@ -458,7 +468,7 @@ extern "C" int vacnic_add_ln_bwd(const vacnic_add_ln_bwd_args* a, void* stream) 
   dim3 grid((unsigned)nb);
   DISPATCH_NCH(nch_for(a->D), add_ln_bwd_kernel, grid, (hipStream_t)stream, (const bf16_t*)a->dout,
                (const bf16_t*)a->x, (const bf16_t*)a->residual, a->gamma, a->mean, a->rstd, (bf16_t*)a->dresidual,
-               (bf16_t*)a->dx, a->dgamma, a->dbeta, a->R, (int)a->D, a->p_drop, a->seed);
+               (bf16_t*)a->dx, a->dgamma, a->dbeta, a->R, (int)a->D, a->p_drop, a->seed, a->seed_dev);
   VLAUNCH_CHECK();
   return VACNIC_OK;
 }
@@ -471,7 +481,7 @@ extern "C" int vacnic_embed_ln_fwd(const vacnic_embed_ln_fwd_args* a, void* stre
   dim3 grid((unsigned)((R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
   DISPATCH_NCH(nch_for(a->D), embed_ln_fwd_kernel, grid, (hipStream_t)stream, a->ids, (const bf16_t*)a->embed,
                (const bf16_t*)a->pos, a->gamma, a->beta, (bf16_t*)a->out, a->mean, a->rstd, R, (int)a->T, (int)a->D,
-               a->V, (int)a->pos_offset, a->embed_scale, a->eps, a->p_drop, a->seed);
+               a->V, (int)a->pos_offset, a->embed_scale, a->eps, a->p_drop, a->seed, a->seed_dev);
   VLAUNCH_CHECK();
   return VACNIC_OK;
 }
@@ -488,7 +498,7 @@ extern "C" int vacnic_embed_ln_bwd(const vacnic_embed_ln_bwd_args* a, void* stre
   DISPATCH_NCH(nch_for(a->D), embed_ln_bwd_kernel, grid, (hipStream_t)stream, a->ids, (const bf16_t*)a->embed,
                (const bf16_t*)a->pos, (const bf16_t*)a->dout, a->gamma, a->mean, a->rstd, a->dembed, a->dpos,
                a->dgamma, a->dbeta, R, (int)a->T, (int)a->D, a->V, (int)a->pos_offset, a->embed_scale,
-               a->padding_idx, a->p_drop, a->seed);
+               a->padding_idx, a->p_drop, a->seed, a->seed_dev);
   VLAUNCH_CHECK();
   return VACNIC_OK;
 }

@@ -7,8 +7,9 @@
 namespace {
 
 // hyper[0] = lr for this step, hyper[1] = step count t (float, 1-based after the increment)
-__global__ void lr_step_kernel(float* hyper, float base_lr, float warmup, float total) {
+__global__ void lr_step_kernel(float* hyper, float base_lr, float warmup, float total, unsigned long long* rng_counter) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
+    if (rng_counter) *rng_counter += 1ull;
     const float k = hyper[1];                 // optimizer steps taken so far == LambdaLR's current_step
     float lam;
     if (k < warmup) lam = k / fmaxf(1.f, warmup);
@@ -62,9 +63,9 @@ inline unsigned grid_for(long work) {
 
 }  // namespace
 
-extern "C" int vacnic_lr_step(float* hyper, float base_lr, float warmup_steps, float total_steps, void* stream) {
+extern "C" int vacnic_lr_step(float* hyper, float base_lr, float warmup_steps, float total_steps, uint64_t* rng_counter, void* stream) {
   VCHECK(hyper, VACNIC_BAD_SHAPE, "lr_step: null hyper");
-  hipLaunchKernelGGL(lr_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, hyper, base_lr, warmup_steps, total_steps);
+  hipLaunchKernelGGL(lr_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, hyper, base_lr, warmup_steps, total_steps, (unsigned long long*)rng_counter);
   VLAUNCH_CHECK();
   return VACNIC_OK;
 }

@@ -81,18 +81,18 @@ def attn_bwd(q, k, v, out, dout, lse, dq, dk, dv, B, H, Tq, Tk, key_mask=None, c
 
 
 # -------------------------------------------------------------------------------------------- LN family
-def add_ln_fwd(x, residual, gamma, beta, eps=1e-5, p_drop=0.0, seed=0, need_stats=True):
+def add_ln_fwd(x, residual, gamma, beta, eps=1e-5, p_drop=0.0, seed=0, need_stats=True, seed_dev=None):
     D = x.shape[-1]
     R = x.numel() // D
     out = torch.empty_like(x)
     mean = torch.empty(R, device=x.device, dtype=torch.float32) if need_stats else None
     rstd = torch.empty(R, device=x.device, dtype=torch.float32) if need_stats else None
     call_struct("vacnic_add_ln_fwd", stream=_stream(), x=_p(x), residual=_p(residual), gamma=_p(gamma), beta=_p(beta),
-                out=_p(out), mean=_p(mean), rstd=_p(rstd), R=R, D=D, eps=eps, p_drop=p_drop, seed=seed)
+                out=_p(out), mean=_p(mean), rstd=_p(rstd), R=R, D=D, eps=eps, p_drop=p_drop, seed=seed, seed_dev=_p(seed_dev))
     return out, mean, rstd
 
 
-def add_ln_bwd(dout, x, residual, gamma, mean, rstd, dgamma, dbeta, p_drop=0.0, seed=0, need_dres=True):
+def add_ln_bwd(dout, x, residual, gamma, mean, rstd, dgamma, dbeta, p_drop=0.0, seed=0, need_dres=True, seed_dev=None):
     D = x.shape[-1]
     R = x.numel() // D
     dx = torch.empty_like(x)
@@ -104,11 +104,11 @@ def add_ln_bwd(dout, x, residual, gamma, mean, rstd, dgamma, dbeta, p_drop=0.0, 
         dres = None            # identical to dx: caller reuses dx
     call_struct("vacnic_add_ln_bwd", stream=_stream(), dout=_p(dout), x=_p(x), residual=_p(residual), gamma=_p(gamma),
                 mean=_p(mean), rstd=_p(rstd), dresidual=_p(dres), dx=_p(dx), dgamma=_p(dgamma), dbeta=_p(dbeta),
-                R=R, D=D, p_drop=p_drop, seed=seed)
+                R=R, D=D, p_drop=p_drop, seed=seed, seed_dev=_p(seed_dev))
     return dx, (dres if dres is not None else dx)
 
 
-def embed_ln_fwd(ids, embed16, pos16, gamma, beta, embed_scale=1.0, pos_offset=2, eps=1e-5, p_drop=0.0, seed=0):
+def embed_ln_fwd(ids, embed16, pos16, gamma, beta, embed_scale=1.0, pos_offset=2, eps=1e-5, p_drop=0.0, seed=0, seed_dev=None):
     B, T = ids.shape
     V, D = embed16.shape
     out = torch.empty((B, T, D), device=ids.device, dtype=BF16)
@@ -116,18 +116,18 @@ def embed_ln_fwd(ids, embed16, pos16, gamma, beta, embed_scale=1.0, pos_offset=2
     rstd = torch.empty(B * T, device=ids.device, dtype=torch.float32)
     call_struct("vacnic_embed_ln_fwd", stream=_stream(), ids=_p(ids), embed=_p(embed16), pos=_p(pos16), gamma=_p(gamma),
                 beta=_p(beta), out=_p(out), mean=_p(mean), rstd=_p(rstd), B=B, T=T, D=D, V=V, pos_offset=pos_offset,
-                embed_scale=embed_scale, eps=eps, p_drop=p_drop, seed=seed)
+                embed_scale=embed_scale, eps=eps, p_drop=p_drop, seed=seed, seed_dev=_p(seed_dev))
     return out, mean, rstd
 
 
 def embed_ln_bwd(ids, embed16, pos16, dout, gamma, mean, rstd, dembed, dpos, dgamma, dbeta, embed_scale=1.0,
-                 pos_offset=2, padding_idx=1, p_drop=0.0, seed=0):
+                 pos_offset=2, padding_idx=1, p_drop=0.0, seed=0, seed_dev=None):
     B, T = ids.shape
     V, D = embed16.shape
     call_struct("vacnic_embed_ln_bwd", stream=_stream(), ids=_p(ids), embed=_p(embed16), pos=_p(pos16), dout=_p(dout),
                 gamma=_p(gamma), mean=_p(mean), rstd=_p(rstd), dembed=_p(dembed), dpos=_p(dpos), dgamma=_p(dgamma),
                 dbeta=_p(dbeta), B=B, T=T, D=D, V=V, pos_offset=pos_offset, embed_scale=embed_scale,
-                padding_idx=padding_idx, p_drop=p_drop, seed=seed)
+                padding_idx=padding_idx, p_drop=p_drop, seed=seed, seed_dev=_p(seed_dev))
 
 
 def name_embed_mean(ids3d, embed16, pos16, gamma, beta, embed_scale=1.0, pos_offset=2, eps=1e-5):
@@ -212,8 +212,8 @@ def secla_bwd(faces, names, sim, l1, l2, grad_out, grad_scale):
 
 
 # ---------------------------------------------------------------------------------------------- optimizer
-def lr_step(hyper, base_lr, warmup, total):
-    call("vacnic_lr_step", hyper.data_ptr(), base_lr, float(warmup), float(total), _stream())
+def lr_step(hyper, base_lr, warmup, total, rng_counter=None):
+    call("vacnic_lr_step", hyper.data_ptr(), base_lr, float(warmup), float(total), _p(rng_counter), _stream())
 
 
 def adamw(p, g, m, v, p16, hyper, n, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, grad_scale=1.0, zero_grad=True):

@@ -37,6 +37,14 @@ class Rng:
         cls.counter += 1
         return (cls.base << 32) | (cls.counter & 0xFFFFFFFF)
 
+    dev = None      # int64 [1] on the GPU: per-step counter mixed into every site seed (incremented by lr_step)
+
+    @classmethod
+    def device_counter(cls):
+        if cls.dev is None:
+            cls.dev = torch.zeros(1, dtype=torch.int64, device="cuda")
+        return cls.dev
+
 
 class LinearSpec:
     """What a GEMM needs to know about an nn.Linear: bf16 shadow weight [N,K], fp32 bias, grad views."""
@@ -225,7 +233,8 @@ class AddLnFn(Function):
         x = _c(x)
         res = _c(residual) if residual is not None else None
         need = ge and any(ctx.needs_input_grad)
-        out, mean, rstd = K.add_ln_fwd(x, res, gamma, beta, p_drop=p_drop, seed=seed, need_stats=need)
+        sd = Rng.device_counter() if p_drop > 0 else None
+        out, mean, rstd = K.add_ln_fwd(x, res, gamma, beta, p_drop=p_drop, seed=seed, need_stats=need, seed_dev=sd)
         ctx.p, ctx.seed = p_drop, seed
         ctx.gb = (gamma, beta)
         ctx.has_res = res is not None
@@ -238,6 +247,7 @@ class AddLnFn(Function):
         x, res, mean, rstd = ctx.saved_tensors
         gamma, beta = ctx.gb
         dx, dres = K.add_ln_bwd(_c(dout), x, res, gamma, mean, rstd, gamma.grad, beta.grad, p_drop=ctx.p, seed=ctx.seed,
+                                seed_dev=Rng.device_counter() if ctx.p > 0 else None,
                                 need_dres=ctx.has_res and ctx.needs_input_grad[1])
         ddp.done(gamma.grad, beta.grad)
         return (dx if ctx.needs_input_grad[0] else None), (dres if ctx.has_res and ctx.needs_input_grad[1] else None), None, None, None, None, None
@@ -253,7 +263,8 @@ class EmbedLnFn(Function):
 
     @staticmethod
     def forward(ctx, ids, tok, pos, gamma, beta, scale, p_drop, seed, padding_idx, ge):
-        out, mean, rstd = K.embed_ln_fwd(ids, tok.w16, pos.w16, gamma, beta, embed_scale=scale, p_drop=p_drop, seed=seed)
+        out, mean, rstd = K.embed_ln_fwd(ids, tok.w16, pos.w16, gamma, beta, embed_scale=scale, p_drop=p_drop, seed=seed,
+                                         seed_dev=Rng.device_counter() if p_drop > 0 else None)
         ctx.args = (tok, pos, gamma, beta, scale, p_drop, seed, padding_idx)
         ctx.save_for_backward(ids, mean, rstd)
         ddp.expect(ge and any(ctx.needs_input_grad), tok.grad, pos.grad, gamma.grad, beta.grad)
@@ -264,7 +275,7 @@ class EmbedLnFn(Function):
         ids, mean, rstd = ctx.saved_tensors
         tok, pos, gamma, beta, scale, p, seed, pad = ctx.args
         K.embed_ln_bwd(ids, tok.w16, pos.w16, _c(dout), gamma, mean, rstd, tok.grad, pos.grad, gamma.grad, beta.grad,
-                       embed_scale=scale, padding_idx=pad, p_drop=p, seed=seed)
+                       embed_scale=scale, padding_idx=pad, p_drop=p, seed=seed, seed_dev=Rng.device_counter() if p > 0 else None)
         ddp.done(tok.grad, pos.grad, gamma.grad, beta.grad)
         return (None,) * 10
 

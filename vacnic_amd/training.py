@@ -47,7 +47,7 @@ class FusedAdamW:
 
     def step(self):
         a = self.arena
-        K.lr_step(self.hyper, self.lr, self.warmup, self.total)
+        K.lr_step(self.hyper, self.lr, self.warmup, self.total, ops.Rng.device_counter())   # also advances the dropout counter
         K.adamw(a.flat32, a.grad, a.exp_avg, a.exp_avg_sq, a.flat16, self.hyper, a.n, self.betas[0], self.betas[1],
                 self.eps, self.wd, grad_scale=1.0 / self.world, zero_grad=True)
 
@@ -168,3 +168,34 @@ def train_step(model, guide, optimizer, batch, args: TrainArgs):
     optimizer.step()
     optimizer.zero_grad()
     return out4
+
+
+class GraphedTrainStep:
+    """The whole training step (all streams: compute, guide, weight gradients) captured once into a hipGraph and
+    replayed per batch — "HIP graphs instead of a tracing compiler".  A step is ~3300 kernel launches; eager Python
+    issues them in ~65-75 ms, which caps throughput once the GPU needs less than that.  Replay costs one launch.
+
+    Capture-safety of the step: no host<->device sync inside it, LR / step counter / dropout counter live in device
+    memory (lr_step kernel), every kernel is launched on torch's current stream (the capture stream or a side stream
+    forked from it by an event), and all scratch comes from torch's graph-private allocator pool.
+    Inputs are copied into static device buffers before each replay (a few hundred KiB of ids + the image batch).
+    Not used with world_size > 1 (RCCL collectives stay outside a captured graph in round 1)."""
+
+    def __init__(self, model, guide, optimizer, args: TrainArgs, example_batch, warmup=2):
+        self.static = {k: v.clone() for k, v in example_batch.items()}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                       # eager warm-up on a side stream (allocator + lazy inits)
+            for _ in range(warmup):
+                train_step(model, guide, optimizer, self.static, args)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out4 = train_step(model, guide, optimizer, self.static, args)
+
+    def __call__(self, batch):
+        for k, v in self.static.items():
+            v.copy_(batch[k], non_blocking=True)
+        self.graph.replay()
+        return self.out4
