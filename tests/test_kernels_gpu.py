@@ -114,6 +114,23 @@ def test_gemm_wgrad_both_kstrided(K, M, N, K_, split):
     close(acc, ref, 2e-3, 2e-2 * math.sqrt(K_ / 256), "wgrad accumulate")
 
 
+def test_gemm_row_split_dispatch(K):
+    """auto dispatch cuts a small row remainder off into its own launch (ViT: M = 32*257 = 8224 = 8192 + 32); all
+    row-indexed operands (out, preact, residual, dact_src, K-strided X) must be offset consistently."""
+    M, N, K_ = 8224, 1024, 128
+    x = rnd(M, K_, seed=1); w = rnd(N, K_, scale=0.1, seed=2); b = rnd(N, dtype=torch.float32, seed=3); res = rnd(M, N, seed=4)
+    pre = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    out = K.gemm(x, w, M, N, K_, bias=b, act="quick_gelu", preact=pre, residual=res)
+    u = x.float() @ w.float().t() + b
+    close(pre, u, 1e-2, 1e-2, "preact across the split"); close(out, u * torch.sigmoid(1.702 * u) + res.float(), 1e-2, 2e-2, "out across the split")
+    d = K.gemm(x, w, M, N, K_, act="gelu", dact_src=pre)
+    uu = pre.float().requires_grad_(True); torch.nn.functional.gelu(uu).backward(x.float() @ w.float().t())
+    close(d, uu.grad, 2e-2, 2e-2, "dact across the split")
+    xt = x.t().contiguous()                                     # [K_, M] K-strided X
+    o32 = K.gemm(xt, w, M, N, K_, x_kstrided=True, out_mode=1)
+    close(o32, x.float() @ w.float().t(), 1e-3, 1e-3, "K-strided X, f32 out across the split")
+
+
 @pytest.mark.parametrize("hint", [64, 128, 256, 257])
 @pytest.mark.parametrize("M,N,K_", [(300, 520, 200), (1024, 768, 512), (257, 255 + 1, 64)])
 def test_gemm_all_layouts_both_tile_configs(K, hint, M, N, K_):

@@ -357,10 +357,67 @@ int launch_gemm(const GemmP& p0, bool xks, bool wks, int zsplits, hipStream_t s)
 
 }  // namespace
 
+// ---- host-side tile selection --------------------------------------------------------------------------------
+// Cost model in "MFMA work units" (bm*bn*k elements): a launch needs ceil(tiles / resident slots) rounds; a round
+// costs the time of one tile with the CU shared by `per_cu` co-resident workgroups, plus a fixed ~10 us of launch /
+// prologue / epilogue (measured: profiles/r1_gemm_overhead.txt), expressed in the same units.
+struct TileCfg { int bm, bn, slots, per_cu; double eff; int hint; };
+static const TileCfg kCfgs[3] = {
+    {256, 256, 256, 1, 1.00, 256},     // 8 waves, 128 KiB LDS, one workgroup per CU
+    {128, 128, 512, 2, 0.80, 128},     // 4 waves, 64 KiB LDS, two per CU
+    {64, 128, 256, 1, 0.42, 64},       // 4 waves, 4-deep ring (96 KiB): latency-bound small problems
+};
+static const double kFixedUnits = 27e6;
+
+static double cfg_cost(const TileCfg& c, int64_t M, int64_t N, int64_t kper, int64_t z) {
+  const int64_t tiles = ((M + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn) * z;
+  const int64_t rounds = (tiles + c.slots - 1) / c.slots;
+  return (double)rounds * ((double)c.per_cu * c.bm * c.bn * (double)kper / c.eff + kFixedUnits);
+}
+
+static int gemm_one(const vacnic_gemm_args* a, int hint, void* stream);
+
 extern "C" int vacnic_gemm_bf16(const vacnic_gemm_args* a, void* stream) {
   VCHECK(a && a->x && a->w && a->out, VACNIC_BAD_SHAPE, "gemm: null operand");
   VCHECK(a->M > 0 && a->N > 0 && a->K > 0, VACNIC_BAD_SHAPE, "gemm: empty problem M=%ld N=%ld K=%ld",
          (long)a->M, (long)a->N, (long)a->K);
+  if (a->tile_hint != 0) return gemm_one(a, a->tile_hint, stream);
+  const int split = a->split_k < 1 ? 1 : a->split_k;
+  int64_t kper = (a->K + split - 1) / split;
+  kper = (kper + BK - 1) / BK * BK;
+  const int64_t z = (a->K + kper - 1) / kper;
+  // best single launch
+  int best = 0; double best_cost = 1e300;
+  for (int i = 0; i < 3; ++i) {
+    if (i == 0 && (a->M < 256 || a->N < 256)) continue;
+    const double c = cfg_cost(kCfgs[i], a->M, a->N, kper, z);
+    if (c < best_cost) { best_cost = c; best = i; }
+  }
+  // M-split: rows are independent, so a small row remainder that would open an extra (almost empty) round is cut off
+  // and run as its own small launch (e.g. the ViT's M = 32*257 = 8224 = 8192 + 32)
+  int split_cfg = -1; int64_t m_main = 0; double split_cost = best_cost;
+  for (int i = 0; i < 2; ++i) {
+    const int64_t rem = a->M % kCfgs[i].bm;
+    if (rem == 0 || a->M - rem < kCfgs[i].bm || (i == 0 && a->N < 256)) continue;
+    const double c = cfg_cost(kCfgs[i], a->M - rem, a->N, kper, z) + cfg_cost(kCfgs[2], rem, a->N, kper, z);
+    if (c < 0.85 * split_cost) { split_cost = c; split_cfg = i; m_main = a->M - rem; }
+  }
+  if (split_cfg < 0) return gemm_one(a, kCfgs[best].hint, stream);
+  vacnic_gemm_args main_a = *a, tail_a = *a;
+  main_a.M = m_main;
+  tail_a.M = a->M - m_main;
+  const int64_t xoff = a->x_kstrided ? m_main : m_main * a->ldx;
+  tail_a.x = (const char*)a->x + xoff * 2;
+  const int64_t osz = a->out_mode == 0 ? 2 : 4;
+  tail_a.out = (char*)a->out + m_main * a->ldo * osz;
+  if (a->preact) tail_a.preact = (char*)a->preact + m_main * a->ldo * 2;
+  if (a->dact_src) tail_a.dact_src = (const char*)a->dact_src + m_main * a->ldo * 2;
+  if (a->residual) tail_a.residual = (const char*)a->residual + m_main * a->ldo * 2;
+  if (int e = gemm_one(&main_a, kCfgs[split_cfg].hint, stream)) return e;
+  return gemm_one(&tail_a, kCfgs[2].hint, stream);
+}
+
+static int gemm_one(const vacnic_gemm_args* a, int tile_hint, void* stream) {
   VCHECK((a->ldx & 7) == 0 && (a->ldw & 7) == 0, VACNIC_MISALIGNED, "gemm: ldx/ldw must be multiples of 8");
   VCHECK(aligned16(a->x) && aligned16(a->w), VACNIC_MISALIGNED, "gemm: x/w must be 16-byte aligned");
   VCHECK(a->out_mode >= 0 && a->out_mode <= 2, VACNIC_BAD_DTYPE, "gemm: bad out_mode %d", a->out_mode);
@@ -395,15 +452,10 @@ extern "C" int vacnic_gemm_bf16(const vacnic_gemm_args* a, void* stream) {
   p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
   p.tiles_m = p.tiles_n = 0;
   hipStream_t s = (hipStream_t)stream;
-  // tile configuration: 256x256 (8 waves, 1 block/CU) when those tiles (times the K-splits) can occupy most of
-  // the 256 CUs; 128x128 (2 blocks/CU) when that fills the chip; otherwise 64x128 with a 4-deep LDS-DMA ring —
-  // small problems put at most one workgroup on a CU, so load latency must be hidden inside the workgroup.
-  const int64_t t256 = ((a->M + 255) / 256) * ((a->N + 255) / 256) * zsplits;
-  const int64_t t128 = ((a->M + 127) / 128) * ((a->N + 127) / 128) * zsplits;
-  const int force = a->tile_hint % 1000;
-  p.debug = a->tile_hint / 1000;
-  const bool big = force == 256 || (force == 0 && a->M >= 256 && a->N >= 256 && t256 >= 192);
-  const bool mid = force == 128 || (force == 0 && t128 >= 384);
+  const int force = tile_hint % 1000;
+  p.debug = tile_hint / 1000;
+  const bool big = force == 256;
+  const bool mid = force == 128;
   if (force == 257) return launch_gemm<256, 128, 2, 2, 32, 3>(p, a->x_kstrided, a->w_kstrided, zsplits, s);   // experimental: 2 blocks/CU
   if (force == 258) return launch_gemm<256, 256, 2, 4, 32, 4>(p, a->x_kstrided, a->w_kstrided, zsplits, s);   // experimental: deeper ring
   if (force == 259) return launch_gemm<256, 256, 2, 4, 32, 3>(p, a->x_kstrided, a->w_kstrided, zsplits, s);

@@ -109,24 +109,43 @@ def to_device(batch, device):
     return {k: v.to(device, non_blocking=True) for k, v in batch.items()}
 
 
-def forward_losses(model, guide, batch, args: TrainArgs):
-    """Forward of one step; returns (total, out4={total, txt, secla*w?, colam}, model_out).  `model` may be the
-    DDP wrapper (like TRAIN:274 `model.module`)."""
+def forward_losses(model, guide, batch, args: TrainArgs, ready=None):
+    """Forward of one step; returns (total, out4={total, txt, secla, colam}, model_out).  `model` may be the DDP wrapper
+    (like TRAIN:274 `model.module`).  `ready`: optional event after which the batch tensors are valid in HBM; with side
+    streams enabled the frozen towers then start on it instead of on the compute stream's tail (= the previous AdamW)."""
     net = model.module if isinstance(model, DistributedDataParallel) else model
     cfg = net.config
     src, tgt = batch["article_ids"], batch["caption_ids"]
-    src_mask, _ = K.prep_ids(src, cfg.pad_token_id)                                          # create_src_mask_bart, TRAIN:268
-    tgt_mask, tgt_in = K.prep_ids(tgt, cfg.pad_token_id, start_id=cfg.eos_token_id)         # shift_tokens_right, TRAIN:267,296
-    # the frozen guide forward is independent of the student until the CoLaM loss: issue it on the aux stream, ahead of
-    # the ViT, so its kernels fill the bubbles of the main chain
-    aux = streams.aux_stream() if guide is not None else None
-    if aux is not None:
-        aux.wait_stream(torch.cuda.current_stream())
+    main = torch.cuda.current_stream()
+    aux, vis = streams.aux_stream(), streams.vit_stream()
+    if aux is None:
+        src_mask, _ = K.prep_ids(src, cfg.pad_token_id)                                      # create_src_mask_bart, TRAIN:268
+        tgt_mask, tgt_in = K.prep_ids(tgt, cfg.pad_token_id, start_id=cfg.eos_token_id)     # shift_tokens_right, TRAIN:267,296
+        _, img_cls = extract_clip_img_feat(net.clip_model, batch["img_tensor"])               # TRAIN:274-276
+    else:
+        # id preprocessing + frozen guide forward on the aux stream, frozen ViT on its own stream: they depend only on
+        # the batch, so they fill the bubbles of the main chain (and of the previous step's AdamW)
+        for s_ in (aux, vis):
+            if ready is None:
+                s_.wait_stream(main)
+            else:
+                s_.wait_event(ready)
         with torch.cuda.stream(aux):
-            gh = guide(input_ids=src, attention_mask=src_mask, decoder_input_ids=tgt_in)["decoder_hidden_states"][-1]   # TRAIN:293-294
-        for tns in (src, src_mask, tgt_in):
+            src_mask, _ = K.prep_ids(src, cfg.pad_token_id)
+            tgt_mask, tgt_in = K.prep_ids(tgt, cfg.pad_token_id, start_id=cfg.eos_token_id)
+            ev_prep = torch.cuda.Event()
+            ev_prep.record(aux)
+            if guide is not None:
+                gh = guide(input_ids=src, attention_mask=src_mask, decoder_input_ids=tgt_in)["decoder_hidden_states"][-1]   # TRAIN:293-294
+        with torch.cuda.stream(vis):
+            _, img_cls = extract_clip_img_feat(net.clip_model, batch["img_tensor"])
+        main.wait_event(ev_prep)
+        main.wait_stream(vis)
+        for tns in (src_mask, tgt_mask, tgt_in, img_cls):
+            tns.record_stream(main)
+        for tns in (src, tgt):
             tns.record_stream(aux)
-    _, img_cls = extract_clip_img_feat(net.clip_model, batch["img_tensor"])                   # TRAIN:274-276
+        batch["img_tensor"].record_stream(vis)
     kw = {}
     if not cfg.only_image:
         names_mask, _ = K.prep_ids(batch["names_art_ids"], cfg.pad_token_id)                 # TRAIN:270
@@ -138,8 +157,8 @@ def forward_losses(model, guide, batch, args: TrainArgs):
     colam = secla = None
     if guide is not None:
         if aux is not None:
-            torch.cuda.current_stream().wait_stream(aux)
-            gh.record_stream(torch.cuda.current_stream())
+            main.wait_stream(aux)
+            gh.record_stream(main)
         else:
             gh = guide(input_ids=src, attention_mask=src_mask, decoder_input_ids=tgt_in)["decoder_hidden_states"][-1]   # TRAIN:293-294
         colam = ops.ColamFn.apply(out["decoder_hidden_states"][-1], gh, tgt_mask, args.margin, args.alpha)        # TRAIN:296-307
@@ -153,12 +172,12 @@ def forward_losses(model, guide, batch, args: TrainArgs):
     return total, out4, out
 
 
-def train_step(model, guide, optimizer, batch, args: TrainArgs):
+def train_step(model, guide, optimizer, batch, args: TrainArgs, ready=None):
     """loss.backward(); optimizer.step(); scheduler.step(); zero_grad()  (TRAIN:364-374) — returns the device-side
     loss vector {total, txt, secla, colam} WITHOUT syncing (the reference's four .item() calls per step are gone)."""
     net = model.module if isinstance(model, DistributedDataParallel) else model
     net.train()
-    total, out4, _ = forward_losses(model, guide, batch, args)
+    total, out4, _ = forward_losses(model, guide, batch, args, ready)
     total.backward()
     streams.join_all()                       # weight-gradient side stream -> compute stream
     if isinstance(model, DistributedDataParallel):
