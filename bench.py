@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=1)
     ap.add_argument("--no-streams", action="store_true", help="single-stream schedule (no side streams for guide / wgrad)")
+    ap.add_argument("--no-tower-graphs", action="store_true", help="launch the frozen guide/ViT forwards eagerly instead of as two hipGraph replays")
     ap.add_argument("--graph", action="store_true", help="replay the step as one captured hipGraph (world 1 only). Measured slower than "
                     "eager multi-stream launches while the step is GPU-bound (91.0 vs 86.2 ms: hipGraph runs the side-stream branches "
                     "less concurrently), so eager is the default")
@@ -160,7 +161,7 @@ def main():
     from vacnic_amd import synthetic
     from vacnic_amd.config import bart_large_vit_l14
     from vacnic_amd.ddp import DistributedDataParallel
-    from vacnic_amd.training import FusedAdamW, GraphedTrainStep, TrainArgs, build_models, to_device, train_step
+    from vacnic_amd.training import FrozenTowerGraphs, FusedAdamW, GraphedTrainStep, TrainArgs, build_models, to_device, train_step
 
     from vacnic_amd import streams
     streams.enable(not a.no_streams)
@@ -180,6 +181,14 @@ def main():
     ready = torch.cuda.Event()
     ready.record()                      # the synthetic batches are resident and complete: frozen towers may start on this
 
+    towers = None
+    if not a.no_streams and not a.no_tower_graphs and not a.graph:
+        try:
+            towers = FrozenTowerGraphs(model, guide, batches[0])
+            log("frozen towers (guide BART, CLIP ViT) captured as hipGraphs")
+        except Exception as e:
+            log(f"tower graph capture failed ({e!r}); eager launches")
+            towers = None
     use_graph = world == 1 and a.graph
     log(f"batches resident; warm-up ({'hipGraph capture' if use_graph else 'eager'})")
     graphed = None
@@ -195,7 +204,7 @@ def main():
             torch.cuda.synchronize()
     if graphed is None:
         for i in range(a.warmup):
-            train_step(net, guide, opt, batches[i % nb], args, ready)
+            train_step(net, guide, opt, batches[i % nb], args, ready, towers)
             torch.cuda.synchronize()
             log(f"warm-up step {i} done")
     if world > 1:
@@ -209,11 +218,11 @@ def main():
         if i == a.steps - 1:
             # last timed step: eager, with HIP events around every GEMM launch (roofline of the dominant kernel)
             timer.install()
-            out4 = train_step(net, guide, opt, bt, args, ready)
+            out4 = train_step(net, guide, opt, bt, args, ready, towers)
         elif graphed is not None:
             out4 = graphed(bt)
         else:
-            out4 = train_step(net, guide, opt, bt, args, ready)
+            out4 = train_step(net, guide, opt, bt, args, ready, towers)
     timer.remove()
     host_dt = time.perf_counter() - t0           # host-side enqueue time of the K steps (GPU may still be running)
     torch.cuda.synchronize()
@@ -261,7 +270,8 @@ def main():
                "config": {"workload": f"BASELINE configs[{1 if world == 1 else 2}]: BART-large + CLIP ViT-L/14 full VACNIC (clipcap P=20, SECLA, CoLaM a=0.5 m=1.0), "
                                       f"224x224 image, {S}-token article, {T}-token caption, per-GPU batch {B}, dropout 0.1, fp32 master + bf16 compute",
                           "global_batch": B * world, "seq_len": S, "caption_len": T, "parallelism": f"dp{world}"},
-               "launch_mode": "hipGraph replay (K-1 steps) + 1 eager instrumented step" if graphed is not None else "eager",
+               "launch_mode": ("hipGraph replay (K-1 steps) + 1 eager instrumented step" if graphed is not None else
+                               "eager multi-stream" + (", frozen towers as hipGraph replays" if towers is not None else "")),
                "host_enqueue_ms_per_step": round(host_dt / a.steps * 1e3, 2),
                "step_tflops_per_gpu": round(value / world * gf / 1e3, 1) if gf else None,
                "step_mfma_frac": round(value / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4) if gf else None,

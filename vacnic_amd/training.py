@@ -109,7 +109,7 @@ def to_device(batch, device):
     return {k: v.to(device, non_blocking=True) for k, v in batch.items()}
 
 
-def forward_losses(model, guide, batch, args: TrainArgs, ready=None):
+def forward_losses(model, guide, batch, args: TrainArgs, ready=None, towers=None):
     """Forward of one step; returns (total, out4={total, txt, secla, colam}, model_out).  `model` may be the DDP wrapper
     (like TRAIN:274 `model.module`).  `ready`: optional event after which the batch tensors are valid in HBM; with side
     streams enabled the frozen towers then start on it instead of on the compute stream's tail (= the previous AdamW)."""
@@ -122,6 +122,14 @@ def forward_losses(model, guide, batch, args: TrainArgs, ready=None):
         src_mask, _ = K.prep_ids(src, cfg.pad_token_id)                                      # create_src_mask_bart, TRAIN:268
         tgt_mask, tgt_in = K.prep_ids(tgt, cfg.pad_token_id, start_id=cfg.eos_token_id)     # shift_tokens_right, TRAIN:267,296
         _, img_cls = extract_clip_img_feat(net.clip_model, batch["img_tensor"])               # TRAIN:274-276
+    elif towers is not None:
+        # frozen towers as two hipGraph replays on their side streams (FrozenTowerGraphs)
+        src_mask, tgt_mask, tgt_in, ev_prep = towers.launch(batch, ready)
+        main.wait_event(ev_prep)
+        main.wait_stream(vis)
+        img_cls, gh = towers.img_cls, towers.gh
+        for tns in (src_mask, tgt_mask, tgt_in):
+            tns.record_stream(main)
     else:
         # id preprocessing + frozen guide forward on the aux stream, frozen ViT on its own stream: they depend only on
         # the batch, so they fill the bubbles of the main chain (and of the previous step's AdamW)
@@ -158,10 +166,13 @@ def forward_losses(model, guide, batch, args: TrainArgs, ready=None):
     if guide is not None:
         if aux is not None:
             main.wait_stream(aux)
-            gh.record_stream(main)
+            if towers is None:
+                gh.record_stream(main)
         else:
             gh = guide(input_ids=src, attention_mask=src_mask, decoder_input_ids=tgt_in)["decoder_hidden_states"][-1]   # TRAIN:293-294
         colam = ops.ColamFn.apply(out["decoder_hidden_states"][-1], gh, tgt_mask, args.margin, args.alpha)        # TRAIN:296-307
+    if towers is not None:
+        towers.mark_consumed()               # static img_cls / gh have been read: the next replay may overwrite them
     if args.use_secla and not args.no_mapping and not cfg.only_image:
         enc = net.model.encoder
         ln = enc.layernorm_embedding_ner
@@ -172,12 +183,12 @@ def forward_losses(model, guide, batch, args: TrainArgs, ready=None):
     return total, out4, out
 
 
-def train_step(model, guide, optimizer, batch, args: TrainArgs, ready=None):
+def train_step(model, guide, optimizer, batch, args: TrainArgs, ready=None, towers=None):
     """loss.backward(); optimizer.step(); scheduler.step(); zero_grad()  (TRAIN:364-374) — returns the device-side
     loss vector {total, txt, secla, colam} WITHOUT syncing (the reference's four .item() calls per step are gone)."""
     net = model.module if isinstance(model, DistributedDataParallel) else model
     net.train()
-    total, out4, _ = forward_losses(model, guide, batch, args, ready)
+    total, out4, _ = forward_losses(model, guide, batch, args, ready, towers)
     total.backward()
     streams.join_all()                       # weight-gradient side stream -> compute stream
     if isinstance(model, DistributedDataParallel):
@@ -218,3 +229,86 @@ class GraphedTrainStep:
             v.copy_(batch[k], non_blocking=True)
         self.graph.replay()
         return self.out4
+
+
+class FrozenTowerGraphs:
+    """hipGraph replay for the two frozen, autograd-free, static-shape networks of the step (guide BART forward and
+    CLIP ViT forward): ~750 of the step's ~3300 launches become two graph launches on their side streams, which takes
+    ~15 ms per step off the Python launch path while the trainable network keeps eager multi-stream launches
+    (a single whole-step graph measured slower: hipGraph runs its parallel branches less concurrently than streams do).
+
+    Static buffers: inputs are copied in on the tower's stream right before the replay; the outputs (`gh`, `img_cls`) are
+    read by the main chain only during the forward pass, so the next replay waits for the `consumed` event recorded
+    after the CoLaM forward (write-after-read), and the id masks the backward needs are fresh tensors every step."""
+
+    def __init__(self, net, guide, example_batch):
+        cfg = net.config
+        self.net, self.guide = net, guide
+        aux, vis = streams.aux_stream(), streams.vit_stream()
+        if aux is None:
+            raise RuntimeError("FrozenTowerGraphs needs streams.enable(True)")
+        torch.cuda.synchronize()
+        self.pad, self.start = cfg.pad_token_id, cfg.eos_token_id
+        self.src_s = example_batch["article_ids"].clone()
+        self.img_s = example_batch["img_tensor"].clone()
+        self.mask_s, _ = K.prep_ids(self.src_s, self.pad)
+        _, self.tgtin_s = K.prep_ids(example_batch["caption_ids"].clone(), self.pad, start_id=self.start)
+        self.consumed = None
+        self.gh = self.g_guide = None
+
+        def guide_body():
+            return guide(input_ids=self.src_s, attention_mask=self.mask_s, decoder_input_ids=self.tgtin_s)["decoder_hidden_states"][-1]
+
+        def vit_body():
+            return extract_clip_img_feat(net.clip_model, self.img_s)[1]
+
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            with torch.cuda.stream(vis):                     # eager warm-up on the capture streams
+                vit_body()
+            if guide is not None:
+                with torch.cuda.stream(aux):
+                    guide_body()
+            torch.cuda.synchronize()
+            if guide is not None:
+                self.g_guide = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.g_guide, stream=aux):
+                    self.gh = guide_body()
+            self.g_vit = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_vit, stream=vis):
+                self.img_cls = vit_body()
+        torch.cuda.synchronize()
+
+    def launch(self, batch, ready):
+        """enqueue id preprocessing (eager, fresh tensors) and both tower replays on their streams."""
+        aux, vis = streams.aux_stream(), streams.vit_stream()
+        main = torch.cuda.current_stream()
+        for s_ in (aux, vis):
+            if ready is None:
+                s_.wait_stream(main)
+            else:
+                s_.wait_event(ready)
+            if self.consumed is not None:
+                s_.wait_event(self.consumed)
+        src, tgt = batch["article_ids"], batch["caption_ids"]
+        with torch.cuda.stream(aux):
+            src_mask, _ = K.prep_ids(src, self.pad)
+            tgt_mask, tgt_in = K.prep_ids(tgt, self.pad, start_id=self.start)
+            ev_prep = torch.cuda.Event()
+            ev_prep.record(aux)
+            if self.g_guide is not None:
+                self.src_s.copy_(src, non_blocking=True)
+                self.mask_s.copy_(src_mask, non_blocking=True)
+                self.tgtin_s.copy_(tgt_in, non_blocking=True)
+                self.g_guide.replay()
+        with torch.cuda.stream(vis):
+            self.img_s.copy_(batch["img_tensor"], non_blocking=True)
+            self.g_vit.replay()
+        for tns in (src, tgt):
+            tns.record_stream(aux)
+        batch["img_tensor"].record_stream(vis)
+        return src_mask, tgt_mask, tgt_in, ev_prep
+
+    def mark_consumed(self):
+        self.consumed = torch.cuda.Event()
+        self.consumed.record(torch.cuda.current_stream())
