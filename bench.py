@@ -216,9 +216,13 @@ def main():
     for i in range(a.steps):
         bt = batches[(a.warmup + i) % nb]
         if i == a.steps - 1:
-            # last timed step: eager, with HIP events around every GEMM launch (roofline of the dominant kernel)
+            # last timed step: single-stream eager launches with HIP events around every GEMM launch, so each bracket times
+            # ONE kernel alone on the GPU (with side streams the brackets would overlap other kernels) — this is the
+            # roofline measurement of the dominant kernel, taken inside the timed region (it costs ~12 ms of throughput once)
+            streams.enable(False)
             timer.install()
-            out4 = train_step(net, guide, opt, bt, args, ready, towers)
+            out4 = train_step(net, guide, opt, bt, args, ready, None)
+            streams.enable(not a.no_streams)
         elif graphed is not None:
             out4 = graphed(bt)
         else:
