@@ -165,7 +165,8 @@ def attn_ref(q, k, v, key_mask, causal, scale):
 SHAPES = [  # B, H, Tq, Tk, masked, causal
     (2, 4, 128, 128, False, False), (2, 3, 200, 200, True, False), (2, 4, 96, 40, False, False),
     (3, 2, 80, 84, True, False), (2, 4, 64, 64, False, True), (2, 2, 64, 300, True, False),
-    (1, 2, 257, 257, False, False), (2, 2, 20, 512, True, False), (1, 16, 512, 512, True, False)]
+    (1, 2, 257, 257, False, False), (2, 2, 20, 512, True, False), (1, 16, 512, 512, True, False),
+    (1, 4, 1024, 1024, True, False), (1, 2, 64, 1024, True, False), (2, 2, 50, 50, False, False)]
 
 
 @pytest.mark.parametrize("B,H,Tq,Tk,masked,causal", SHAPES)

@@ -288,3 +288,58 @@ def test_beam_topk_kernel_matches_torch():
     idx = torch.tensor([5, 0, 0, 3, 2, 1]).cuda()
     K.gather_rows(src, dst, idx, 6, 64 * 4)
     assert torch.equal(dst, src[idx])
+
+
+def test_cfg1_bart_base_vit_b32_only_image_full_depth_matches_oracle():
+    """BASELINE configs[0]: BART-base + CLIP ViT-B/32, --only_image (TRAINV/MVIS path), batch 2, S=512, T=64 — the full-size
+    plumbing case: ViT features -> prompt -> 6+6 layers -> CE, HIP vs the CPU oracle on the same seeded weights/batch."""
+    from oracle import vacnic_oracle as O
+    from vacnic_amd import synthetic
+    from vacnic_amd.config import bart_base_vit_b32
+    from vacnic_amd.training import TrainArgs, build_models, forward_losses, to_device
+    cfg, vcfg = bart_base_vit_b32(dropout=0.0)
+    model, _, _ = build_models(cfg, vcfg, init="synthetic", seed=0)
+    model.eval()
+    batch = synthetic.make_batch(cfg, 2, S=512, T=64, seed=21)
+    with torch.no_grad():
+        total, out4, out = forward_losses(model, None, to_device(batch, "cuda"), TrainArgs(use_secla=False))
+    sd = synthetic.make_state_dict(synthetic.mmbart_param_shapes(cfg), seed=1)
+    sd_c = synthetic.make_state_dict(synthetic.clip_visual_param_shapes(vcfg), seed=4, std=0.05)
+    with torch.no_grad():
+        ref = O.train_losses(sd, None, sd_c, cfg, vcfg, batch, use_secla=False)
+    got, want = out4[1].item(), ref["txt"].item()
+    assert abs(got - want) <= 1e-2 * abs(want), (got, want)
+    assert abs(out4[0].item() - ref["loss"].item()) <= 1e-2 * abs(ref["loss"].item())
+    r = rel(out["hidden_states_img"], ref["out"]["hidden_states_img"])
+    assert r < 2e-2, r
+
+
+def test_cfg4_long_article_1024_tokens_step_and_oracle():
+    """BASELINE configs[3]: NYTimes800k-shaped 1024-token article.  (a) 2-layer BART-large-width model at S=1024 against the
+    oracle; (b) properties at full cfg4 width/depth on a small batch: finite losses, loss falls on a repeated batch."""
+    from oracle import vacnic_oracle as O
+    from vacnic_amd import synthetic
+    from vacnic_amd.config import ClipVisionConfig, VacnicConfig, bart_large_vit_l14
+    from vacnic_amd.training import FusedAdamW, TrainArgs, build_models, forward_losses, to_device, train_step
+    cfg = VacnicConfig(encoder_layers=2, decoder_layers=2, enc_fusion_layer=[0, 1], clip_width=1024, dropout=0.0).validate()
+    vcfg = ClipVisionConfig(width=1024, layers=1, patch_size=14, image_size=28, output_dim=64)
+    model, guide, _ = build_models(cfg, vcfg, init="synthetic", seed=0)
+    model.eval()
+    batch = synthetic.make_batch(cfg, 2, S=1024, T=64, seed=31, image_size=28)
+    with torch.no_grad():
+        _, out4, _ = forward_losses(model, guide, to_device(batch, "cuda"), TrainArgs())
+    sds = [synthetic.make_state_dict(f(cfg), seed=s) for f, s in ((synthetic.mmbart_param_shapes, 1), (synthetic.guide_bart_param_shapes, 2))]
+    sd_c = synthetic.make_state_dict(synthetic.clip_visual_param_shapes(vcfg), seed=4, std=0.05)
+    with torch.no_grad():
+        ref = O.train_losses(sds[0], sds[1], sd_c, cfg, vcfg, batch)
+    for i, k in ((0, "loss"), (1, "txt"), (2, "secla"), (3, "colam")):
+        assert abs(out4[i].item() - ref[k].item()) <= 1e-2 * abs(ref[k].item()) + 1e-3, (k, out4[i].item(), ref[k].item())
+    del model, guide
+    torch.cuda.empty_cache()
+    cfg4, vcfg4 = bart_large_vit_l14(dropout=0.0)
+    model, guide, _ = build_models(cfg4, vcfg4, init="device", seed=3)
+    opt = FusedAdamW(model.arena, lr=1e-4, num_warmup_steps=0, num_training_steps=100)
+    b4 = to_device(synthetic.make_batch(cfg4, 2, S=1024, T=64, seed=32, full_length=True), "cuda")
+    hist = [train_step(model, guide, opt, b4, TrainArgs(num_training_steps=100)).tolist() for _ in range(4)]
+    assert all(np.isfinite(h).all() for h in hist), hist
+    assert hist[-1][1] < hist[0][1], hist
