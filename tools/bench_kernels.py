@@ -33,17 +33,17 @@ def main():
         x = r(M, Kd); w = r(N, Kd); b = torch.zeros(N, device=dev)
         ldo = (N + 31) // 32 * 32
         out = torch.empty(M, ldo, device=dev, dtype=torch.bfloat16)
-        for hint in (256, 258, 259):
+        for hint in (256, 260, 128, 261):
             t = timeit(lambda: K.gemm(x, w, M, N, Kd, bias=b, out=out, ldo=ldo, tile_hint=hint))
             res.append((f"gemm fwd t{hint} {name}", t, 2 * M * N * Kd / t / 1e12, "TF/s"))
         if N <= 4096:
             dy = r(M, N)
             dx = torch.empty(M, Kd, device=dev, dtype=torch.bfloat16)
-            for hint in (256, 258, 259):
+            for hint in (256, 260, 128, 261):
                 t = timeit(lambda: K.gemm(dy, w, M, Kd, N, out=dx, w_kstrided=True, tile_hint=hint))
                 res.append((f"gemm dgrad t{hint} {name}", t, 2 * M * N * Kd / t / 1e12, "TF/s"))
             dw = torch.zeros(N, Kd, device=dev)
-            for hint, sp in ((128, K.wgrad_split(M, ((N + 127) // 128) * ((Kd + 127) // 128))), (256, max(1, 256 // (((N + 255) // 256) * ((Kd + 255) // 256)))), (256, max(1, 512 // (((N + 255) // 256) * ((Kd + 255) // 256))))):
+            for hint, sp in ((128, K.wgrad_split(M, ((N + 127) // 128) * ((Kd + 127) // 128))), (261, K.wgrad_split(M, ((N + 127) // 128) * ((Kd + 127) // 128))), (256, max(1, 256 // (((N + 255) // 256) * ((Kd + 255) // 256)))), (260, max(1, 256 // (((N + 255) // 256) * ((Kd + 255) // 256))))):
                 t = timeit(lambda: K.gemm(dy, x, N, Kd, M, out=dw, x_kstrided=True, w_kstrided=True, out_mode=2, split_k=sp, tile_hint=hint))
                 res.append((f"gemm wgrad t{hint} split {sp} {name}", t, 2 * M * N * Kd / t / 1e12, "TF/s"))
     # attention

@@ -186,7 +186,7 @@ __device__ __forceinline__ void epilogue8(const GemmP& p, float v[8], int m, int
 template <int N>
 __device__ __forceinline__ void wait_vm_lgkm() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
 
-template <int BM, int BN, int WM, int WN, int BKT, int NSTAGE, bool XKS, bool WKS>
+template <int BM, int BN, int WM, int WN, int BKT, int NSTAGE, bool PIPE, bool XKS, bool WKS>
 __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
   constexpr int NWAVE = WM * WN, NTHR = 64 * NWAVE;
   constexpr int TM = BM / WM, TN = BN / WN;             // per-wave output sub-tile
@@ -238,6 +238,51 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
   wait_vm_lgkm<LOADS * (NSTAGE - 2)>();                  // tile 0 landed
   __builtin_amdgcn_s_barrier();
   int cur = 0, nxt = NSTAGE - 1;
+  if constexpr (PIPE && BKT == 64) {
+    // Software-pipelined K loop: the barrier sits in the MIDDLE of a tile's MFMA work.  The fragments of (t, kk=1) are
+    // in registers before the barrier, so after it the wave issues the LDS reads of (t+1, kk=0) and covers their
+    // latency (and the barrier skew between the 8 waves) with the 32..64 MFMAs of (t, kk=1).  Two fragment sets.
+    bf16x8 xf0[FA], wf0[FB], xf1[FA], wf1[FB];
+#pragma unroll
+    for (int a = 0; a < FA; ++a) xf0[a] = read_frag<XKS, BM, BKT>(smem, wm * TM + a * 16, 0, lane);
+#pragma unroll
+    for (int b = 0; b < FB; ++b) wf0[b] = read_frag<WKS, BN, BKT>(smem + XT, wn * TN + b * 16, 0, lane);
+    for (int t = 0; t < ntile; ++t) {
+      char* xcur = smem + cur * STAGE;
+      char* wcur = xcur + XT;
+      {
+        char* xnext = smem + nxt * STAGE;
+        stage_tile<XKS, BM, BKT, NWAVE>(xs, xnext, m0, RX, kbeg + (t + NSTAGE - 1) * BKT, kend, p.ldx, wave, lane);
+        stage_tile<WKS, BN, BKT, NWAVE>(ws, xnext + XT, n0, RW, kbeg + (t + NSTAGE - 1) * BKT, kend, p.ldw, wave, lane);
+      }
+#pragma unroll
+      for (int a = 0; a < FA; ++a) xf1[a] = read_frag<XKS, BM, BKT>(xcur, wm * TM + a * 16, 1, lane);
+#pragma unroll
+      for (int b = 0; b < FB; ++b) wf1[b] = read_frag<WKS, BN, BKT>(wcur, wn * TN + b * 16, 1, lane);
+#pragma unroll
+      for (int b = 0; b < FB; ++b)
+#pragma unroll
+        for (int a = 0; a < FA; ++a)
+          acc[b][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[b], xf0[a], acc[b][a], 0, 0, 0);
+      // tile t+1 landed (this wave's loads), every LDS read of this slot (incl. the kk=1 fragments) retired
+      wait_vm_lgkm<LOADS * (NSTAGE - 2)>();
+      __builtin_amdgcn_s_barrier();
+      cur = cur + 1 == NSTAGE ? 0 : cur + 1;
+      nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
+      {
+        const char* xn = smem + cur * STAGE;           // tile t+1 (zero-filled past the end: harmless)
+#pragma unroll
+        for (int a = 0; a < FA; ++a) xf0[a] = read_frag<XKS, BM, BKT>(xn, wm * TM + a * 16, 0, lane);
+#pragma unroll
+        for (int b = 0; b < FB; ++b) wf0[b] = read_frag<WKS, BN, BKT>(xn + XT, wn * TN + b * 16, 0, lane);
+      }
+#pragma unroll
+      for (int b = 0; b < FB; ++b)
+#pragma unroll
+        for (int a = 0; a < FA; ++a)
+          acc[b][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[b], xf1[a], acc[b][a], 0, 0, 0);
+    }
+  } else {
   for (int t = 0; t < ntile; ++t) {
     char* xcur = smem + cur * STAGE;
     char* wcur = xcur + XT;
@@ -265,6 +310,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
     __builtin_amdgcn_s_barrier();
     cur = cur + 1 == NSTAGE ? 0 : cur + 1;
     nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
+  }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the (zero-fill) tail loads before LDS is reused
   __builtin_amdgcn_s_barrier();
@@ -330,7 +376,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, int BKT, int NSTAGE>
+template <int BM, int BN, int WM, int WN, int BKT, int NSTAGE, bool PIPE = false>
 int launch_gemm(const GemmP& p0, bool xks, bool wks, int zsplits, hipStream_t s) {
   GemmP p = p0;
   p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
@@ -339,7 +385,7 @@ int launch_gemm(const GemmP& p0, bool xks, bool wks, int zsplits, hipStream_t s)
   static_assert(lds >= 64 * (BN + 4) * 4, "epilogue staging must fit in the operand buffers");
 #define VAC_LAUNCH(XK, WK)                                                                            \
   do {                                                                                                \
-    auto kern = gemm_kernel<BM, BN, WM, WN, BKT, NSTAGE, XK, WK>;                                                  \
+    auto kern = gemm_kernel<BM, BN, WM, WN, BKT, NSTAGE, (PIPE && (XK || WK || BM >= 256)), XK, WK>;   /* pipelined loop pays for transposed-read operands */                                                  \
     if (lds > 65536) {                                                                                \
       static bool once = false;                                                                       \
       if (!once) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; } \
@@ -459,7 +505,9 @@ static int gemm_one(const vacnic_gemm_args* a, int tile_hint, void* stream) {
   if (force == 257) return launch_gemm<256, 128, 2, 2, 32, 3>(p, a->x_kstrided, a->w_kstrided, zsplits, s);   // experimental: 2 blocks/CU
   if (force == 258) return launch_gemm<256, 256, 2, 4, 32, 4>(p, a->x_kstrided, a->w_kstrided, zsplits, s);   // experimental: deeper ring
   if (force == 259) return launch_gemm<256, 256, 2, 4, 32, 3>(p, a->x_kstrided, a->w_kstrided, zsplits, s);
-  if (big) return launch_gemm<256, 256, 2, 4, 64, 2>(p, a->x_kstrided, a->w_kstrided, zsplits, s);
-  if (mid) return launch_gemm<128, 128, 2, 2, 64, 2>(p, a->x_kstrided, a->w_kstrided, zsplits, s);
+  if (force == 260) return launch_gemm<256, 256, 2, 4, 64, 2, false>(p, a->x_kstrided, a->w_kstrided, zsplits, s);   // plain (non-pipelined) K loop, for A/B
+  if (force == 261) return launch_gemm<128, 128, 2, 2, 64, 2, false>(p, a->x_kstrided, a->w_kstrided, zsplits, s);
+  if (big) return launch_gemm<256, 256, 2, 4, 64, 2, true>(p, a->x_kstrided, a->w_kstrided, zsplits, s);
+  if (mid) return launch_gemm<128, 128, 2, 2, 64, 2, true>(p, a->x_kstrided, a->w_kstrided, zsplits, s);
   return launch_gemm<64, 128, 2, 2, 64, 4>(p, a->x_kstrided, a->w_kstrided, zsplits, s);
 }
