@@ -154,10 +154,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and world == 1:
         raise SystemExit("launch with torch.distributed.run for --gpus > 1 (one process per GPU)")
-    torch.cuda.set_device(local)
+    # VACNIC_DIST_BACKEND=gloo VACNIC_SINGLE_DEVICE=1: rehearse the N>1 code path (tracker, bucket launches, side streams,
+    # joins) with several ranks sharing ONE GPU — RCCL itself needs one GPU per rank, which only the driver's node has
+    single_dev = os.environ.get("VACNIC_SINGLE_DEVICE") == "1"
+    backend = os.environ.get("VACNIC_DIST_BACKEND", "nccl")
+    torch.cuda.set_device(0 if single_dev else local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     from vacnic_amd import synthetic
     from vacnic_amd.config import bart_large_vit_l14
     from vacnic_amd.ddp import DistributedDataParallel

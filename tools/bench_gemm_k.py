@@ -8,7 +8,7 @@ r = lambda *s: (torch.randn(*s, device=dev) * 0.5).bfloat16()
 M, N = 16384, 1024
 for Kd in (64, 1024):
     x = r(M, Kd); w = r(N, Kd); out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-    for hint in (256, 1256, 2256, 3256, 128, 1128):
+    for hint in (256, 3256, 6256, 8256, 8128, 8064):
         t = timeit(lambda: K.gemm(x, w, M, N, Kd, out=out, tile_hint=hint), iters=50)
         print(f"K={Kd:5d} t{hint}: {t*1e6:7.1f} us  {2*M*N*Kd/t/1e12:7.1f} TF/s")
 # pure copy of the same output volume for reference

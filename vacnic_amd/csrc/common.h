@@ -39,16 +39,17 @@ static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0;
 
 // ---- bf16 <-> f32 ------------------------------------------------------------------------------
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
-// round-to-nearest-even; NaN stays NaN (quietened)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+// f32 -> bf16, round-to-nearest-even, NaN stays NaN: ONE v_cvt_pk_bf16_f32 per two values (gfx950).  The integer
+// rounding idiom costs ~7 VALU instructions per element, which made the GEMM's LDS-staged epilogue take ~8 us per 256x256
+// tile (profiles/r1_gemm_overhead.txt) — more than the first-tile load and the launch together.
+// (written as a __bf16 vector conversion, not inline asm: the compiler then also pads the MFMA-result -> VALU hazards)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_native;
+typedef __attribute__((ext_vector_type(2))) float f32x2_native;
 __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
-  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+  const f32x2_native f = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2_native));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 
 // ---- wave64 reductions ---------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
