@@ -188,7 +188,7 @@ __device__ __forceinline__ void epilogue8(const GemmP& p, float v[8], int m, int
 template <int N>
 __device__ __forceinline__ void wait_vm_lgkm() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
 
-template <int BM, int BN, int WM, int WN, int BKT, int NSTAGE, bool PIPE, bool XKS, bool WKS>
+template <int BM, int BN, int WM, int WN, int BKT, int NSTAGE, bool PIPE, bool STAGGER, bool XKS, bool WKS>
 __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
   constexpr int NWAVE = WM * WN, NTHR = 64 * NWAVE;
   constexpr int TM = BM / WM, TN = BN / WN;             // per-wave output sub-tile
@@ -233,19 +233,80 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
   // all out-of-range -> zero fill, never read) so the counted vmcnt below is a compile-time constant.
   constexpr int LOADS = (BM + BN) * BKT * 2 / 1024 / NWAVE;   // LDS-DMA instructions per wave per K-tile
   static_assert(LOADS * (NSTAGE - 2) <= 63, "vmcnt immediate");
+  constexpr bool PIPED = PIPE && BKT == 64 && NSTAGE == 2;
+  constexpr int PRO = PIPED ? 2 : NSTAGE - 1;            // tiles staged before the loop
 #pragma unroll
-  for (int s = 0; s < NSTAGE - 1; ++s) {
+  for (int s = 0; s < PRO; ++s) {
     stage_tile<XKS, BM, BKT, NWAVE>(xs, smem + s * STAGE, m0, RX, kbeg + s * BKT, kend, p.ldx, wave, lane);
     stage_tile<WKS, BN, BKT, NWAVE>(ws, smem + s * STAGE + XT, n0, RW, kbeg + s * BKT, kend, p.ldw, wave, lane);
   }
-  wait_vm_lgkm<LOADS * (NSTAGE - 2)>();                  // tile 0 landed
+  wait_vm_lgkm<LOADS * (PRO - 1)>();                     // tile 0 landed
   __builtin_amdgcn_s_barrier();
   int cur = 0, nxt = NSTAGE - 1;
-  if constexpr (PIPE && BKT == 64) {
-    // Software-pipelined K loop: the barrier sits in the MIDDLE of a tile's MFMA work.  The fragments of (t, kk=1) are
-    // in registers before the barrier, so after it the wave issues the LDS reads of (t+1, kk=0) and covers their
-    // latency (and the barrier skew between the 8 waves) with the 32..64 MFMAs of (t, kk=1).  Two fragment sets.
+  if constexpr (PIPE && BKT == 32 && NSTAGE == 4) {
+    // Ping-pong K loop (8 waves, two per SIMD; 32-wide K stages in a 4-slot ring).  The waves of a workgroup form two
+    // groups, A = waves 0..3 and B = waves 4..7 (SIMD partners), that run the same sequence one interval apart:
+    //     A:  MEM(0) | COMP(0) | MEM(1) | COMP(1) | ...
+    //     B:    -    | MEM(0)  | COMP(0)| MEM(1)  | ...          ('|' = workgroup barrier)
+    // MEM(h)  = 12 ds_read_b128 (the fragments of stage h) + this wave's 4 LDS-DMA pieces of stage h+3 + counted wait,
+    // COMP(h) = 32 back-to-back MFMAs.  In every interval one wave per SIMD owns the matrix pipe while its partner owns the
+    // LDS / vector-memory issue ports, so neither the fragment reads nor the ~60-100-cycle issue cost of an LDS-DMA piece
+    // ever stalls the MFMA stream (measured before: MFMA-only loop 1.0 us per 64-K, +0.27 us for the LDS reads, +0.34 us
+    // for the DMA issue when both partners do the same thing at the same time).
+    // Ring safety: stage j is read by A in interval 2j and by B in interval 2j+1; MEM(j+1) (intervals 2j+2 / 2j+3) refills
+    // its slot with stage j+4.  A wave leaves MEM(h) only when its own pieces of stage h+1 have landed (vmcnt(8): stages
+    // h+2, h+3 may fly), and a barrier separates that from every later reader.
+    static_assert(NWAVE == 8 && LOADS == 4, "ping-pong loop is written for the 256x256 / 8-wave configuration");
+    const bool grp_b = wave >= NWAVE / 2;
+    const int nst = ntile;
+    bf16x8 xf[FA], wf[FB];
+    if (grp_b) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+    int rd = 0, wr = 3;
+    for (int h = 0; h < nst; ++h) {
+      const char* xr = smem + rd * STAGE;
+      if (!(p.debug & 128) || h == 0) {
+#pragma unroll
+        for (int a = 0; a < FA; ++a) xf[a] = read_frag<XKS, BM, BKT>(xr, wm * TM + a * 16, 0, lane);
+#pragma unroll
+        for (int b = 0; b < FB; ++b) wf[b] = read_frag<WKS, BN, BKT>(xr + XT, wn * TN + b * 16, 0, lane);
+      }
+      if (!(p.debug & 32)) {
+        char* xw = smem + wr * STAGE;
+        stage_tile<XKS, BM, BKT, NWAVE>(xs, xw, m0, RX, kbeg + (h + 3) * BKT, kend, p.ldx, wave, lane);
+        stage_tile<WKS, BN, BKT, NWAVE>(ws, xw + XT, n0, RW, kbeg + (h + 3) * BKT, kend, p.ldw, wave, lane);
+      }
+      wait_vm_lgkm<2 * LOADS>();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int b = 0; b < FB; ++b)
+#pragma unroll
+        for (int a = 0; a < FA; ++a)
+          acc[b][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b], xf[a], acc[b][a], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      rd = (rd + 1) & 3;
+      wr = (wr + 1) & 3;
+    }
+    if (!grp_b) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+  } else if constexpr (PIPED) {
+    // Software-pipelined K loop, two LDS slots.  Per tile t:
+    //   read frags (t, kk=1) | MFMA (t, kk=0) | wait tile t+1 landed + BARRIER | issue LDS-DMA of tile t+2 into slot t |
+    //   read frags (t+1, kk=0) | MFMA (t, kk=1)
+    // - the barrier sits in the middle of the tile's MFMA work: after it the LDS reads of the next tile (and the barrier
+    //   skew of the 8 waves) are covered by the 32..64 MFMAs of (t, kk=1);
+    // - at the barrier every fragment of tile t is already in registers, so slot t is free: the loads of tile t+2 are
+    //   issued right behind it and have a FULL iteration to land (a 64 KiB tile needs ~0.9 us at the per-CU L2->LDS rate
+    //   plus latency; a load issued half an iteration before its wait stalls the whole workgroup);
+    // - SIMD partners (waves w and w+NWAVE/2) issue their LDS-DMA pieces at different points of the iteration (STAGGER:
+    //   right behind the barrier / in the middle of the kk=1 MFMAs), so one keeps the matrix pipe busy while the other
+    //   pays the ~45-cycle issue cost per piece.
     bf16x8 xf0[FA], wf0[FB], xf1[FA], wf1[FB];
+    const bool late = STAGGER && wave >= NWAVE / 2;
 #pragma unroll
     for (int a = 0; a < FA; ++a) xf0[a] = read_frag<XKS, BM, BKT>(smem, wm * TM + a * 16, 0, lane);
 #pragma unroll
@@ -253,11 +314,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
     for (int t = 0; t < ntile; ++t) {
       char* xcur = smem + cur * STAGE;
       char* wcur = xcur + XT;
-      {
-        char* xnext = smem + nxt * STAGE;
-        stage_tile<XKS, BM, BKT, NWAVE>(xs, xnext, m0, RX, kbeg + (t + NSTAGE - 1) * BKT, kend, p.ldx, wave, lane);
-        stage_tile<WKS, BN, BKT, NWAVE>(ws, xnext + XT, n0, RW, kbeg + (t + NSTAGE - 1) * BKT, kend, p.ldw, wave, lane);
-      }
 #pragma unroll
       for (int a = 0; a < FA; ++a) xf1[a] = read_frag<XKS, BM, BKT>(xcur, wm * TM + a * 16, 1, lane);
 #pragma unroll
@@ -267,11 +323,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
 #pragma unroll
         for (int a = 0; a < FA; ++a)
           acc[b][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[b], xf0[a], acc[b][a], 0, 0, 0);
-      // tile t+1 landed (this wave's loads), every LDS read of this slot (incl. the kk=1 fragments) retired
-      wait_vm_lgkm<LOADS * (NSTAGE - 2)>();
+      // tile t+1 landed (all of this wave's loads), every LDS read of slot t retired
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      cur = cur + 1 == NSTAGE ? 0 : cur + 1;
-      nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
+      if (!late) {
+        stage_tile<XKS, BM, BKT, NWAVE>(xs, xcur, m0, RX, kbeg + (t + 2) * BKT, kend, p.ldx, wave, lane);
+        stage_tile<WKS, BN, BKT, NWAVE>(ws, wcur, n0, RW, kbeg + (t + 2) * BKT, kend, p.ldw, wave, lane);
+      }
+      cur ^= 1;
       {
         const char* xn = smem + cur * STAGE;           // tile t+1 (zero-filled past the end: harmless)
 #pragma unroll
@@ -280,28 +339,40 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
         for (int b = 0; b < FB; ++b) wf0[b] = read_frag<WKS, BN, BKT>(xn + XT, wn * TN + b * 16, 0, lane);
       }
 #pragma unroll
-      for (int b = 0; b < FB; ++b)
+      for (int b = 0; b < FB / 2; ++b)
+#pragma unroll
+        for (int a = 0; a < FA; ++a)
+          acc[b][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[b], xf1[a], acc[b][a], 0, 0, 0);
+      if (late) {
+        stage_tile<XKS, BM, BKT, NWAVE>(xs, xcur, m0, RX, kbeg + (t + 2) * BKT, kend, p.ldx, wave, lane);
+        stage_tile<WKS, BN, BKT, NWAVE>(ws, wcur, n0, RW, kbeg + (t + 2) * BKT, kend, p.ldw, wave, lane);
+      }
+#pragma unroll
+      for (int b = FB / 2; b < FB; ++b)
 #pragma unroll
         for (int a = 0; a < FA; ++a)
           acc[b][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[b], xf1[a], acc[b][a], 0, 0, 0);
     }
   } else {
+  bf16x8 xf[FA], wf[FB];
   for (int t = 0; t < ntile; ++t) {
     char* xcur = smem + cur * STAGE;
     char* wcur = xcur + XT;
-    {
+    if (!(p.debug & 32)) {
       // ring slot `nxt` was last read in iteration t-1 and every wave has passed that iteration's barrier
       char* xnext = smem + nxt * STAGE;
       stage_tile<XKS, BM, BKT, NWAVE>(xs, xnext, m0, RX, kbeg + (t + NSTAGE - 1) * BKT, kend, p.ldx, wave, lane);
       stage_tile<WKS, BN, BKT, NWAVE>(ws, xnext + XT, n0, RW, kbeg + (t + NSTAGE - 1) * BKT, kend, p.ldw, wave, lane);
     }
+    if (!(p.debug & 64))
 #pragma unroll
     for (int kk = 0; kk < BKT / 32; ++kk) {
-      bf16x8 xf[FA], wf[FB];
+      if (!(p.debug & 128) || t == 0) {
 #pragma unroll
-      for (int a = 0; a < FA; ++a) xf[a] = read_frag<XKS, BM, BKT>(xcur, wm * TM + a * 16, kk, lane);
+        for (int a = 0; a < FA; ++a) xf[a] = read_frag<XKS, BM, BKT>(xcur, wm * TM + a * 16, kk, lane);
 #pragma unroll
-      for (int b = 0; b < FB; ++b) wf[b] = read_frag<WKS, BN, BKT>(wcur, wn * TN + b * 16, kk, lane);
+        for (int b = 0; b < FB; ++b) wf[b] = read_frag<WKS, BN, BKT>(wcur, wn * TN + b * 16, kk, lane);
+      }
 #pragma unroll
       for (int b = 0; b < FB; ++b)
 #pragma unroll
@@ -319,6 +390,39 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
   __builtin_amdgcn_s_barrier();
 
   if (p.debug & 4) { if (acc[0][0][0] == 12345.678f) ((float*)p.out)[0] = 0.f; return; }
+  // ---- direct epilogue for the common plain case (bf16 out, bias + activation only): each lane owns 4 consecutive n of
+  // one m per accumulator tile -> bias as one 16-byte load, pack with v_cvt_pk_bf16_f32, one 8-byte store.  No LDS
+  // round trip, no barriers; the 32-byte row pieces of the four n-groups are merged by the L2.
+  if (BM <= 128 && p.out_mode == 0 && !p.preact && !p.dact_src && !p.residual && (p.ldo & 3) == 0 && !(p.debug & 16)) {
+    const int lm_ = lane & 15, ln4_ = (lane >> 4) * 4;
+    const bool add_bias_ = p.bias != nullptr;
+#pragma unroll
+    for (int a = 0; a < FA; ++a) {
+      const int m = m0 + wm * TM + a * 16 + lm_;
+      if (m >= p.M) continue;
+      bf16_t* orow = (bf16_t*)p.out + (size_t)m * p.ldo;
+#pragma unroll
+      for (int b = 0; b < FB; ++b) {
+        const int n = n0 + wn * TN + b * 16 + ln4_;
+        if (n + 4 <= p.N) {
+          f32x4 v = acc[b][a];
+          if (p.alpha != 1.0f) v *= p.alpha;
+          if (add_bias_) v += *(const f32x4*)(p.bias + n);
+          if (p.act != VACNIC_ACT_NONE) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = act_fwd(p.act, v[j]);
+          }
+          *(u32x2*)(orow + n) = (u32x2){pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+        } else if (n < p.N) {
+          for (int j = 0; j < 4 && n + j < p.N; ++j) {
+            float v = acc[b][a][j] * p.alpha + (add_bias_ ? p.bias[n + j] : 0.f);
+            orow[n + j] = f2bf(act_fwd(p.act, v));
+          }
+        }
+      }
+    }
+    return;
+  }
   // ---- epilogue: stage the fp32 C tile through LDS (the operand buffers are free now) in 64-row
   // passes, then every thread handles 8 consecutive n of one row: 16-byte coalesced traffic for the
   // output, the saved pre-activation, the activation-backward source and the residual.
@@ -380,7 +484,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, int BKT, int NSTAGE, bool PIPE = false>
+template <int BM, int BN, int WM, int WN, int BKT, int NSTAGE, bool PIPE = false, bool STAGGER = false>
 int launch_gemm(const GemmP& p0, bool xks, bool wks, int zsplits, hipStream_t s) {
   GemmP p = p0;
   p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
@@ -389,7 +493,7 @@ int launch_gemm(const GemmP& p0, bool xks, bool wks, int zsplits, hipStream_t s)
   static_assert(lds >= 64 * (BN + 4) * 4, "epilogue staging must fit in the operand buffers");
 #define VAC_LAUNCH(XK, WK)                                                                            \
   do {                                                                                                \
-    auto kern = gemm_kernel<BM, BN, WM, WN, BKT, NSTAGE, (PIPE && (XK || WK || BM >= 256)), XK, WK>;   /* pipelined loop pays for transposed-read operands */                                                  \
+    auto kern = gemm_kernel<BM, BN, WM, WN, BKT, NSTAGE, PIPE, STAGGER, XK, WK>;                                                  \
     if (lds > 65536) {                                                                                \
       static bool once = false;                                                                       \
       if (!once) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; } \
@@ -511,7 +615,9 @@ static int gemm_one(const vacnic_gemm_args* a, int tile_hint, void* stream) {
   if (force == 259) return launch_gemm<256, 256, 2, 4, 32, 3>(p, a->x_kstrided, a->w_kstrided, zsplits, s);
   if (force == 260) return launch_gemm<256, 256, 2, 4, 64, 2, false>(p, a->x_kstrided, a->w_kstrided, zsplits, s);   // plain (non-pipelined) K loop, for A/B
   if (force == 261) return launch_gemm<128, 128, 2, 2, 64, 2, false>(p, a->x_kstrided, a->w_kstrided, zsplits, s);
-  if (big) return launch_gemm<256, 256, 2, 4, 64, 2, true>(p, a->x_kstrided, a->w_kstrided, zsplits, s);
+  if (force == 263) return launch_gemm<256, 256, 2, 4, 64, 2, true, true>(p, a->x_kstrided, a->w_kstrided, zsplits, s);   // 64-wide pipelined loop, staggered DMA issue (A/B)
+  if (force == 262) return launch_gemm<256, 256, 2, 4, 64, 2, true, false>(p, a->x_kstrided, a->w_kstrided, zsplits, s);   // pipelined, no stagger
+  if (big) return launch_gemm<256, 256, 2, 4, 32, 4, true>(p, a->x_kstrided, a->w_kstrided, zsplits, s);   // ping-pong loop
   if (mid) return launch_gemm<128, 128, 2, 2, 64, 2, true>(p, a->x_kstrided, a->w_kstrided, zsplits, s);
   return launch_gemm<64, 128, 2, 2, 64, 4>(p, a->x_kstrided, a->w_kstrided, zsplits, s);
 }
