@@ -69,11 +69,14 @@ def _wgrad(dy2d, x2d, spec, M):
         ddp.done(spec.wgrad, spec.bgrad)
         return
     side.wait_stream(torch.cuda.current_stream())          # dy / x were produced on the compute stream
-    with torch.cuda.stream(side):
-        _wgrad_impl(dy2d, x2d, spec, M)
-        ddp.done(spec.wgrad, spec.bgrad)
-    dy2d.record_stream(side)
-    x2d.record_stream(side)
+    if ddp.TRACKER is None:
+        with K.launch_on(streams.wgrad_raw()):
+            _wgrad_impl(dy2d, x2d, spec, M)
+    else:
+        with torch.cuda.stream(side):                      # the bucket launcher reads torch's current stream
+            _wgrad_impl(dy2d, x2d, spec, M)
+            ddp.done(spec.wgrad, spec.bgrad)
+    streams.keep(dy2d, x2d)                                # alive until the compute stream joins the side stream
 
 
 def _wgrad_impl(dy2d, x2d, spec, M):

@@ -8,17 +8,20 @@ streams so the hardware can schedule their workgroups into those bubbles:
     frozen CLIP ViT forward; both depend only on the batch, NOT on the weights AdamW is still updating, so when the
     caller vouches for the batch (`ready` event) they start while the previous step's AdamW is running;
   * every weight-gradient GEMM + bias-gradient reduction of the backward pass — needed only by AdamW / the DDP reducer.
-Ordering is by events; tensors that cross streams are handed to the caching allocator with record_stream().
+Ordering is by events.  Tensors consumed on the weight-gradient stream are kept alive by `keep()` until the compute
+stream has joined that stream (`join_all`), NOT by Tensor.record_stream(): with recorded blocks outstanding the caching
+allocator polls their events on every allocation, which cost ~14 us per torch.empty (16 ms of host time per step).
 """
 import torch
 
-_state = {"enabled": False, "wgrad": None, "aux": None, "vit": None}
+_state = {"enabled": False, "wgrad": None, "aux": None, "vit": None, "wgrad_raw": None, "keep": []}
 
 
 def enable(flag=True):
     _state["enabled"] = bool(flag) and torch.cuda.is_available()
     if _state["enabled"] and _state["wgrad"] is None:
         _state["wgrad"] = torch.cuda.Stream()
+        _state["wgrad_raw"] = _state["wgrad"].cuda_stream
         _state["aux"] = torch.cuda.Stream()
         _state["vit"] = torch.cuda.Stream()
 
@@ -29,6 +32,20 @@ def enabled():
 
 def wgrad_stream():
     return _state["wgrad"] if _state["enabled"] else None
+
+
+def wgrad_raw():
+    return _state["wgrad_raw"]
+
+
+def keep(*tensors):
+    """hold references to tensors a side stream is still reading; released by join_all().  Bounded: past 8192 entries the
+    compute stream joins the weight-gradient stream early."""
+    k = _state["keep"]
+    k.extend(tensors)
+    if len(k) > 8192:
+        torch.cuda.current_stream().wait_stream(_state["wgrad"])
+        k.clear()
 
 
 def aux_stream():
@@ -46,3 +63,4 @@ def join_all():
         cur.wait_stream(_state["wgrad"])
         cur.wait_stream(_state["aux"])
         cur.wait_stream(_state["vit"])
+        _state["keep"].clear()          # everything the side streams read is now ordered before later compute-stream work

@@ -187,7 +187,8 @@ def train_step(model, guide, optimizer, batch, args: TrainArgs, ready=None, towe
     """loss.backward(); optimizer.step(); scheduler.step(); zero_grad()  (TRAIN:364-374) — returns the device-side
     loss vector {total, txt, secla, colam} WITHOUT syncing (the reference's four .item() calls per step are gone)."""
     net = model.module if isinstance(model, DistributedDataParallel) else model
-    net.train()
+    if not net.training:
+        net.train()
     total, out4, _ = forward_losses(model, guide, batch, args, ready, towers)
     total.backward()
     streams.join_all()                       # weight-gradient side stream -> compute stream
