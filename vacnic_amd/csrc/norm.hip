@@ -29,15 +29,18 @@ __device__ __forceinline__ void store8(bf16_t* p, const float v[8]) {
   u32x4 r = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
   *(u32x4*)p = r;
 }
-// keep-scale factors for the 8 elements starting at flat index idx (multiple of 8)
+// keep-scale factors for the 8 elements starting at flat index idx (multiple of 8): ONE Philox4x32-10 block per 8 elements,
+// 16 random bits per element (drop probability quantised to 2^-16) — the LayerNorm backward is VALU-bound on the mask
+// recompute, and 32-bit draws (two blocks per 8 elements) cost it 10 us per 16384x1024 launch.
 __device__ __forceinline__ void drop8(uint64_t seed, uint64_t idx, uint32_t thr, float inv_keep, float m[8]) {
   uint32_t b[4];
-  dropout_bits4(seed, idx >> 2, b);
+  dropout_bits4(seed, idx >> 3, b);
+  const uint32_t thr16 = thr >> 16;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) m[i] = b[i] >= thr ? inv_keep : 0.f;
-  dropout_bits4(seed, (idx >> 2) + 1, b);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) m[4 + i] = b[i] >= thr ? inv_keep : 0.f;
+  for (int i = 0; i < 4; ++i) {
+    m[2 * i] = (b[i] & 0xffffu) >= thr16 ? inv_keep : 0.f;
+    m[2 * i + 1] = (b[i] >> 16) >= thr16 ? inv_keep : 0.f;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -117,8 +120,8 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const bf16_t* __restric
 //   dxhat = dout*gamma; dh = rstd*(dxhat - mean(dxhat) - xhat*mean(dxhat*xhat))
 // Each block walks a strided set of rows and keeps per-column dgamma/dbeta partials in registers,
 // then one f32 atomic per column per block.
-template <int NCH>
-__global__ __launch_bounds__(256) void add_ln_bwd_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ x,
+template <int NCH, int NW>
+__global__ __launch_bounds__(64 * NW) void add_ln_bwd_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ x,
                                                          const bf16_t* __restrict__ res, const float* __restrict__ gamma,
                                                          const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                          bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
@@ -136,9 +139,10 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const bf16_t* __restric
 #pragma unroll
     for (int j = 0; j < 8; ++j) { dg[i][j] = 0.f; db[i][j] = 0.f; }
 
-  for (int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave; row < R; row += (int64_t)gridDim.x * ROWS_PER_BLOCK) {
+  for (int64_t row = (int64_t)blockIdx.x * NW + wave; row < R; row += (int64_t)gridDim.x * NW) {
     const float mean = mean_i[row], rstd = rstd_i[row];
-    float xh[NCH][8], dxh[NCH][8], msk[NCH][8];
+    float xh[NCH][8], dxh[NCH][8];
+    uint32_t keep[NCH];                      // dropout keep bits (one register per chunk instead of 8 scale factors)
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
@@ -147,9 +151,12 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const bf16_t* __restric
         float xv[8], dv[8];
         load8(x + row * D + c * 8, xv);
         if (p_drop > 0.f) {
-          drop8(seed, (uint64_t)row * D + c * 8, thr, inv_keep, msk[i]);
+          float m[8];
+          drop8(seed, (uint64_t)row * D + c * 8, thr, inv_keep, m);
+          uint32_t kb = 0;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) xv[j] *= msk[i][j];
+          for (int j = 0; j < 8; ++j) { xv[j] *= m[j]; kb |= (m[j] != 0.f ? 1u : 0u) << j; }
+          keep[i] = kb;
         }
         if (res) {
           float rv[8];
@@ -182,7 +189,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const bf16_t* __restric
         if (dx) {
           if (p_drop > 0.f) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) dh[j] *= msk[i][j];
+            for (int j = 0; j < 8; ++j) dh[j] = (keep[i] >> j) & 1u ? dh[j] * inv_keep : 0.f;
           }
           store8(dx + row * D + c * 8, dh);
         }
@@ -190,7 +197,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const bf16_t* __restric
     }
   }
   // cross-wave reduce of dgamma/dbeta through LDS, then one atomic per column per block
-  __shared__ float red[ROWS_PER_BLOCK][64 * 8 + 1];
+  __shared__ float red[NW][64 * 8 + 1];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
 #pragma unroll
@@ -201,10 +208,12 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const bf16_t* __restric
       __syncthreads();
       float* dst = pass == 0 ? dgamma : dbeta;
       if (dst) {
-        for (int e = threadIdx.x; e < 512; e += 256) {
+        for (int e = threadIdx.x; e < 512; e += 64 * NW) {
           const int c = (e >> 3) + 64 * i;
           if (c < nchunk) {
-            float t = red[0][e] + red[1][e] + red[2][e] + red[3][e];
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) t += red[w][e];
             atomicAdd(dst + c * 8 + (e & 7), t);
           }
         }
@@ -463,12 +472,32 @@ extern "C" int vacnic_add_ln_bwd(const vacnic_add_ln_bwd_args* a, void* stream) 
   VCHECK(a && a->dout && a->x && a->gamma && a->mean && a->rstd, VACNIC_BAD_SHAPE, "add_ln_bwd: null operand");
   if (int e = check_d(a->D, "add_ln_bwd")) return e;
   if (a->R == 0) return VACNIC_OK;
-  int64_t nb = (a->R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
-  if (nb > 1024) nb = 1024;
-  dim3 grid((unsigned)nb);
-  DISPATCH_NCH(nch_for(a->D), add_ln_bwd_kernel, grid, (hipStream_t)stream, (const bf16_t*)a->dout,
-               (const bf16_t*)a->x, (const bf16_t*)a->residual, a->gamma, a->mean, a->rstd, (bf16_t*)a->dresidual,
-               (bf16_t*)a->dx, a->dgamma, a->dbeta, a->R, (int)a->D, a->p_drop, a->seed, a->seed_dev);
+  const hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_LN_BWD(NCH_, NW_, NB_)                                                                                  \
+  hipLaunchKernelGGL((add_ln_bwd_kernel<NCH_, NW_>), dim3((unsigned)(NB_)), dim3(64 * NW_), 0, st, (const bf16_t*)a->dout, \
+                     (const bf16_t*)a->x, (const bf16_t*)a->residual, a->gamma, a->mean, a->rstd, (bf16_t*)a->dresidual, \
+                     (bf16_t*)a->dx, a->dgamma, a->dbeta, a->R, (int)a->D, a->p_drop, a->seed, a->seed_dev)
+  const int nch = nch_for(a->D);
+  if (a->R >= 8192) {
+    int64_t nb = (a->R + 15) / 16;
+    if (nb > 256) nb = 256;
+    switch (nch) {
+      case 1: LAUNCH_LN_BWD(1, 16, nb); break;
+      case 2: LAUNCH_LN_BWD(2, 16, nb); break;
+      case 3: LAUNCH_LN_BWD(3, 16, nb); break;
+      default: LAUNCH_LN_BWD(4, 16, nb); break;
+    }
+  } else {
+    int64_t nb = (a->R + 3) / 4;
+    if (nb > 1024) nb = 1024;
+    switch (nch) {
+      case 1: LAUNCH_LN_BWD(1, 4, nb); break;
+      case 2: LAUNCH_LN_BWD(2, 4, nb); break;
+      case 3: LAUNCH_LN_BWD(3, 4, nb); break;
+      default: LAUNCH_LN_BWD(4, 4, nb); break;
+    }
+  }
+#undef LAUNCH_LN_BWD
   VLAUNCH_CHECK();
   return VACNIC_OK;
 }

@@ -67,14 +67,41 @@ def _row_stride(t):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
+GEMM_LOG = None           # tools/autotune_gemm.py sets this to a list to record call signatures
+GEMM_TUNED = {}           # "xk,wk,M,N,K,out_mode,has_preact" -> [tile_hint, split_k, ...] measured winners (gemm_tuned.json)
+
+
+def _load_tuned():
+    import json, os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tuned.json")
+    if os.path.exists(path) and os.environ.get("VACNIC_GEMM_TUNED", "1") != "0":
+        with open(path) as f:
+            GEMM_TUNED.update(json.load(f))
+
+
+_load_tuned()
+
+
 def gemm(x, w, M, N, K, *, bias=None, out=None, ldx=None, ldw=None, ldo=None, x_kstrided=False, w_kstrided=False,
          act=None, out_mode=0, split_k=1, alpha=1.0, preact=None, dact_src=None, residual=None, tile_hint=0):
-    """out[m][n] = epi(alpha * sum_k X(m,k) W(n,k) + bias[n]) — see include/vacnic_hip.h."""
+    """out[m][n] = epi(alpha * sum_k X(m,k) W(n,k) + bias[n]) — see include/vacnic_hip.h.
+    tile_hint 0: measured winner for this exact shape if gemm_tuned.json has one, else the C-side cost model; -1: cost model."""
     if out is None:
         out = torch.empty((M, N), device=x.device, dtype=BF16 if out_mode == 0 else torch.float32)
     ldx = ldx if ldx is not None else (M if x_kstrided else K)
     ldw = ldw if ldw is not None else (N if w_kstrided else K)
     ldo = ldo if ldo is not None else N
+    if GEMM_LOG is not None:
+        GEMM_LOG.append((int(x_kstrided), int(w_kstrided), M, N, K, ldx, ldw, ldo, out_mode, split_k, bias is not None, act,
+                         preact is not None, dact_src is not None, residual is not None))
+    if tile_hint == 0 and GEMM_TUNED:
+        t = GEMM_TUNED.get(f"{int(x_kstrided)},{int(w_kstrided)},{M},{N},{K},{out_mode},{int(preact is not None)}")
+        if t is not None:
+            tile_hint = t[0] or -1
+            if out_mode == 2:
+                split_k = t[1]
+    if tile_hint < 0:
+        tile_hint = 0
     call_struct("vacnic_gemm_bf16", stream=_stream(), x=_p(x), w=_p(w), bias=_p(bias), out=_p(out), preact=_p(preact),
                 dact_src=_p(dact_src), residual=_p(residual), M=M, N=N, K=K, ldx=ldx, ldw=ldw, ldo=ldo,
                 x_kstrided=int(x_kstrided), w_kstrided=int(w_kstrided), act=ACT[act], out_mode=out_mode,
