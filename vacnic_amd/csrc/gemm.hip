@@ -119,6 +119,53 @@ __device__ __forceinline__ void store8bf(bf16_t* p, const float v[8]) {
   *(u32x4*)p = (u32x4){pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
 }
 
+__device__ __forceinline__ void unpack8bf(u32x4 r, float v[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(r[i] << 16); v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u); }
+}
+
+// 8 consecutive, fully in-range, 16-byte-aligned outputs of one row.  Bias and the raw residual / activation-source words
+// were loaded by the caller (batched over all of a thread's chunks, so their latency overlaps).
+__device__ __forceinline__ void epilogue8_vec(const GemmP& p, float v[8], size_t off, const float bia[8], u32x4 rraw, u32x4 draw) {
+  if (p.alpha != 1.0f) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= p.alpha;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] += bia[j];
+  if (p.preact) store8bf(p.preact + off, v);
+  if (p.dact_src) {
+    float d[8];
+    unpack8bf(draw, d);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= act_bwd(p.act, d[j]);
+  } else if (p.act != VACNIC_ACT_NONE) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = act_fwd(p.act, v[j]);
+  }
+  if (p.residual) {
+    float d[8];
+    unpack8bf(rraw, d);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += d[j];
+  }
+  if (p.debug & 1) {
+    if (v[0] == 12345.678f) ((bf16_t*)p.out)[off] = 0;
+  } else if (p.out_mode == 0) {
+    store8bf((bf16_t*)p.out + off, v);
+  } else if (p.out_mode == 1) {
+    float* o = (float*)p.out + off;
+    *(f32x4*)o = (f32x4){v[0], v[1], v[2], v[3]};
+    *(f32x4*)(o + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+  } else {
+    float* o = (float*)p.out + off;
+    f32x4 a0 = *(f32x4*)o, a1 = *(f32x4*)(o + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a0[j] += v[j]; a1[j] += v[4 + j]; }
+    *(f32x4*)o = a0; *(f32x4*)(o + 4) = a1;
+  }
+}
+
 __device__ __forceinline__ void epilogue8(const GemmP& p, float v[8], int m, int n, bool add_bias, bool vec_ok) {
   const size_t off = (size_t)m * p.ldo + n;
   const int nv = min(8, p.N - n);
@@ -257,6 +304,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
     // its slot with stage j+4.  A wave leaves MEM(h) only when its own pieces of stage h+1 have landed (vmcnt(8): stages
     // h+2, h+3 may fly), and a barrier separates that from every later reader.
     static_assert(NWAVE == 8 && LOADS == 4, "ping-pong loop is written for the 256x256 / 8-wave configuration");
+    // DMA placement (STAGGER template flag reused as the switch): false = all four pieces in MEM(h); true = the X pieces in
+    // MEM(h), the W pieces in the middle of COMP(h) — MEM carries 12 ds_reads + its wait already, and a phase pair is as long
+    // as its longer half.
+    constexpr bool SPLIT_DMA = STAGGER;
     const bool grp_b = wave >= NWAVE / 2;
     const int nst = ntile;
     bf16x8 xf[FA], wf[FB];
@@ -264,6 +315,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
     int rd = 0, wr = 3;
     for (int h = 0; h < nst; ++h) {
       const char* xr = smem + rd * STAGE;
+      char* xw = smem + wr * STAGE;
       if (!(p.debug & 128) || h == 0) {
 #pragma unroll
         for (int a = 0; a < FA; ++a) xf[a] = read_frag<XKS, BM, BKT>(xr, wm * TM + a * 16, 0, lane);
@@ -271,17 +323,27 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
         for (int b = 0; b < FB; ++b) wf[b] = read_frag<WKS, BN, BKT>(xr + XT, wn * TN + b * 16, 0, lane);
       }
       if (!(p.debug & 32)) {
-        char* xw = smem + wr * STAGE;
         stage_tile<XKS, BM, BKT, NWAVE>(xs, xw, m0, RX, kbeg + (h + 3) * BKT, kend, p.ldx, wave, lane);
-        stage_tile<WKS, BN, BKT, NWAVE>(ws, xw + XT, n0, RW, kbeg + (h + 3) * BKT, kend, p.ldw, wave, lane);
+        if (!SPLIT_DMA) stage_tile<WKS, BN, BKT, NWAVE>(ws, xw + XT, n0, RW, kbeg + (h + 3) * BKT, kend, p.ldw, wave, lane);
       }
-      wait_vm_lgkm<2 * LOADS>();
+      // stage h+1 must have landed (this wave's pieces); newer ones may fly
+      wait_vm_lgkm<SPLIT_DMA ? 3 * LOADS / 2 : 2 * LOADS>();
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int b = 0; b < FB; ++b)
+      for (int b = 0; b < FB / 2; ++b)
+#pragma unroll
+        for (int a = 0; a < FA; ++a)
+          acc[b][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b], xf[a], acc[b][a], 0, 0, 0);
+      if (SPLIT_DMA && !(p.debug & 32)) {
+        __builtin_amdgcn_sched_barrier(0);
+        stage_tile<WKS, BN, BKT, NWAVE>(ws, xw + XT, n0, RW, kbeg + (h + 3) * BKT, kend, p.ldw, wave, lane);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int b = FB / 2; b < FB; ++b)
 #pragma unroll
         for (int a = 0; a < FA; ++a)
           acc[b][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b], xf[a], acc[b][a], 0, 0, 0);
@@ -432,6 +494,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
   constexpr int PASSES = (BM + 63) / 64;
   const bool vec_ok = (p.ldo & 7) == 0;
   const bool add_bias = blockIdx.z == 0;
+  float bia[8];
 #pragma unroll
   for (int pass = 0; pass < PASSES; ++pass) {
     // every 16-row group of this wave that falls into rows [pass*64, pass*64+64) of the block tile is deposited
@@ -467,17 +530,60 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
       __syncthreads();
       continue;
     }
+    // every thread owns ONE 8-wide column group (NTHR is a multiple of the chunks per row) and RPT rows of the pass: the LDS
+    // reads and the residual / activation-source loads of all RPT chunks are issued before any of them is consumed, and the
+    // bias is loaded once per kernel — a chunk-at-a-time loop exposed one L2 round trip per chunk (7-9 us per tile).
     constexpr int CPR = BN / 8;               // 8-wide chunks per row
-#pragma unroll 1
-    for (int chunk = tid; chunk < 64 * CPR; chunk += NTHR) {
-      const int row = chunk / CPR, c8 = (chunk % CPR) * 8;
-      const int m = m0 + pass * 64 + row, n = n0 + c8;
-      if (m < p.M && n < p.N) {
-        float v[8];
+    constexpr int RPT = 64 * CPR / NTHR;      // chunks per thread per pass
+    constexpr int RSTEP = NTHR / CPR;
+    static_assert((64 * CPR) % NTHR == 0 && NTHR % CPR == 0, "epilogue chunk mapping");
+    const int c8 = (tid % CPR) * 8, rbase = tid / CPR;
+    const int n = n0 + c8;
+    const bool fast = vec_ok && n + 8 <= p.N && (p.out_mode == 0 || (p.ldo & 3) == 0);
+    if (fast) {
+      if (pass == 0) {
+        if (p.bias && add_bias) {
+          const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { bia[j] = b0[j]; bia[4 + j] = b1[j]; }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bia[j] = 0.f;
+        }
+      }
+      float v[RPT][8];
+      u32x4 rraw[RPT], draw[RPT];
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        const int row = rbase + k * RSTEP;
+        const int m = m0 + pass * 64 + row;
         const f32x4 v0 = *(const f32x4*)(sc + row * CLD + c8), v1 = *(const f32x4*)(sc + row * CLD + c8 + 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { v[j] = v0[j]; v[4 + j] = v1[j]; }
-        epilogue8(p, v, m, n, add_bias, vec_ok);
+        for (int j = 0; j < 4; ++j) { v[k][j] = v0[j]; v[k][4 + j] = v1[j]; }
+        rraw[k] = (u32x4){0, 0, 0, 0}; draw[k] = (u32x4){0, 0, 0, 0};
+        if (m < p.M) {
+          const size_t off = (size_t)m * p.ldo + n;
+          if (p.residual) rraw[k] = *(const u32x4*)(p.residual + off);
+          if (p.dact_src) draw[k] = *(const u32x4*)(p.dact_src + off);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        const int m = m0 + pass * 64 + rbase + k * RSTEP;
+        if (m < p.M) epilogue8_vec(p, v[k], (size_t)m * p.ldo + n, bia, rraw[k], draw[k]);
+      }
+    } else if (n < p.N) {
+#pragma unroll 1
+      for (int k = 0; k < RPT; ++k) {
+        const int row = rbase + k * RSTEP;
+        const int m = m0 + pass * 64 + row;
+        if (m < p.M) {
+          float v[8];
+          const f32x4 v0 = *(const f32x4*)(sc + row * CLD + c8), v1 = *(const f32x4*)(sc + row * CLD + c8 + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { v[j] = v0[j]; v[4 + j] = v1[j]; }
+          epilogue8(p, v, m, n, add_bias, vec_ok);
+        }
       }
     }
     __syncthreads();
@@ -612,7 +718,7 @@ static int gemm_one(const vacnic_gemm_args* a, int tile_hint, void* stream) {
   const bool mid = force == 128;
   if (force == 257) return launch_gemm<256, 128, 2, 2, 32, 3>(p, a->x_kstrided, a->w_kstrided, zsplits, s);   // experimental: 2 blocks/CU
   if (force == 258) return launch_gemm<256, 256, 2, 4, 32, 4>(p, a->x_kstrided, a->w_kstrided, zsplits, s);   // experimental: deeper ring
-  if (force == 259) return launch_gemm<256, 256, 2, 4, 32, 3>(p, a->x_kstrided, a->w_kstrided, zsplits, s);
+  if (force == 259) return launch_gemm<256, 256, 2, 4, 32, 4, true, true>(p, a->x_kstrided, a->w_kstrided, zsplits, s);   // ping-pong, W pieces issued mid-COMP (A/B)
   if (force == 260) return launch_gemm<256, 256, 2, 4, 64, 2, false>(p, a->x_kstrided, a->w_kstrided, zsplits, s);   // plain (non-pipelined) K loop, for A/B
   if (force == 261) return launch_gemm<128, 128, 2, 2, 64, 2, false>(p, a->x_kstrided, a->w_kstrided, zsplits, s);
   if (force == 263) return launch_gemm<256, 256, 2, 4, 64, 2, true, true>(p, a->x_kstrided, a->w_kstrided, zsplits, s);   // 64-wide pipelined loop, staggered DMA issue (A/B)
