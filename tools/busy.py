@@ -26,3 +26,20 @@ for s, e, _, qq in sel: q[qq] += (e - s) / 1e6
 for k, v in sorted(q.items(), key=lambda x: -x[1]): print(f"  queue {k}: {v:.2f} ms busy")
 gaps.sort(reverse=True)
 print("largest idle gaps (us @ offset ms):", [(round(g / 1e3, 1), round(o / 1e6, 2)) for g, o in gaps[:12]], "total idle in gaps", round(sum(g for g, _ in gaps) / 1e6, 2), "ms")
+
+# ---- main-queue view: idle gaps between consecutive kernels of the busiest queue, with their neighbours
+mainq = max(q.items(), key=lambda x: x[1])[0]
+mk = sorted((s, e, n) for s, e, n, qq in sel if qq == mainq)
+gl = []
+for (s0, e0, n0), (s1, e1, n1) in zip(mk, mk[1:]):
+    if s1 > e0: gl.append((s1 - e0, n0[:48], n1[:48], (e0 - t0) / 1e6))
+tot = sum(g[0] for g in gl) / 1e6
+print(f"main queue {mainq}: {len(mk)} launches, busy {sum(e - s for s, e, _ in mk)/1e6:.2f} ms, idle between launches {tot:.2f} ms")
+import collections as C
+hist = C.Counter()
+for g in gl:
+    b = 2 if g[0] < 2e3 else 5 if g[0] < 5e3 else 10 if g[0] < 1e4 else 50 if g[0] < 5e4 else 1000
+    hist[b] += g[0] / 1e6
+print("idle by gap size (<2us,<5us,<10us,<50us,more) ms:", [round(hist[b], 2) for b in (2, 5, 10, 50, 1000)])
+for g in sorted(gl, reverse=True)[:15]:
+    print(f"  {g[0]/1e3:8.1f} us at {g[3]:7.2f} ms  after {g[1]}  before {g[2]}")

@@ -190,7 +190,8 @@ def train_step(model, guide, optimizer, batch, args: TrainArgs, ready=None, towe
     if not net.training:
         net.train()
     total, out4, _ = forward_losses(model, guide, batch, args, ready, towers)
-    total.backward()
+    with torch.autograd.set_multithreading_enabled(False):     # one device: the engine's worker-thread hop only costs host time
+        total.backward()
     streams.join_all()                       # weight-gradient side stream -> compute stream
     if isinstance(model, DistributedDataParallel):
         model.reduce_gradients()
@@ -297,14 +298,15 @@ class FrozenTowerGraphs:
             tgt_mask, tgt_in = K.prep_ids(tgt, self.pad, start_id=self.start)
             ev_prep = torch.cuda.Event()
             ev_prep.record(aux)
-            if self.g_guide is not None:
+        with torch.cuda.stream(vis):                 # the student's encoder input needs the image feature: ViT goes first
+            self.img_s.copy_(batch["img_tensor"], non_blocking=True)
+            self.g_vit.replay()
+        if self.g_guide is not None:
+            with torch.cuda.stream(aux):             # the guide's output is needed only by the CoLaM loss
                 self.src_s.copy_(src, non_blocking=True)
                 self.mask_s.copy_(src_mask, non_blocking=True)
                 self.tgtin_s.copy_(tgt_in, non_blocking=True)
                 self.g_guide.replay()
-        with torch.cuda.stream(vis):
-            self.img_s.copy_(batch["img_tensor"], non_blocking=True)
-            self.g_vit.replay()
         for tns in (src, tgt):
             tns.record_stream(aux)
         batch["img_tensor"].record_stream(vis)
