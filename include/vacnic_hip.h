@@ -67,7 +67,7 @@ typedef struct {
   int32_t x_kstrided, w_kstrided;
   int32_t act, out_mode, split_k;
   float alpha;
-  int32_t tile_hint;              /* 0 = library picks by problem size; 64 (64x128, 4-deep ring) / 128 / 256 force a tile config */
+  int32_t tile_hint;              /* 0 = library picks by problem size (M <= 8 rows: the W-streaming skinny kernel); 8 (skinny) / 64 (64x128, 4-deep ring) / 128 / 256 force a config */
 } vacnic_gemm_args;
 int vacnic_gemm_bf16(const vacnic_gemm_args* a, void* stream);
 

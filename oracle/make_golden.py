@@ -197,6 +197,10 @@ def run_generate_case(mfull, train):
     from transformers import GenerationMixin
     cfg = small_cfg(encoder_layers=1, decoder_layers=1)
     sd = synthetic.make_state_dict(synthetic.mmbart_param_shapes(cfg), seed=1)
+    # N(0, 0.02) weights give almost flat next-token distributions (top-2 margins far below bf16 resolution, so any two
+    # correct implementations order the beams differently); scaling the tied embedding/LM-head matrix spreads the logits
+    # (std ~3) the way a trained model does, which makes "identical ids" a meaningful, stable bar
+    sd["model.shared.weight"] = sd["model.shared.weight"] * synthetic.GEN_SHARPEN
 
     class Oracle(mfull.BartForMultiModalGeneration, GenerationMixin):
         pass
@@ -284,6 +288,9 @@ def run_clip_crosscheck():
 def main():
     os.makedirs(OUT, exist_ok=True)
     mfull, mvis, train, BatchSoftmax = import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "generate":
+        run_generate_case(mfull, train)
+        return
     run_helpers(train, BatchSoftmax)
     run_generate_case(mfull, train)
     run_clip_crosscheck()

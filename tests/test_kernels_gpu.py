@@ -205,6 +205,27 @@ def test_attention_fully_masked_row_is_uniform(K):
     close(out, v.float().mean(1, keepdim=True).expand(B, Tq, 64), 1e-2, 1e-2, "all-masked row = uniform softmax like torch")
 
 
+@pytest.mark.parametrize("B,H,Tk,masked", [(5, 16, 1, False), (5, 16, 37, False), (8, 12, 512, True), (3, 4, 600, True), (2, 2, 64, True)])
+def test_attention_single_query_decode_path(K, B, H, Tk, masked):
+    """Tq == 1 (KV-cached decoder step): one-wave-per-(row, head) kernel; strided cache views, key mask, lse, all-masked row."""
+    d = H * 64
+    q = rnd(B, 1, 3 * d, seed=1)[..., 2 * d:]
+    cache = rnd(B, Tk + 3, 2 * d, seed=2)                       # cache longer than the valid prefix
+    k = cache[:, :Tk, :d]; v = cache[:, :Tk, d:]
+    mask = None
+    if masked:
+        lens = torch.randint(1, Tk + 1, (B,), generator=torch.Generator().manual_seed(3))
+        lens[0] = 0                                              # fully masked row -> uniform softmax
+        mask = (torch.arange(Tk)[None, :] < lens[:, None]).to(torch.uint8).cuda()
+    out, lse = K.attn_fwd(q, k, v, B, H, 1, Tk, key_mask=mask, scale=0.125)
+    ref = attn_ref(q.float().reshape(B, 1, H, 64), k.float().reshape(B, Tk, H, 64), v.float().reshape(B, Tk, H, 64), mask, False, 0.125)
+    close(out, ref, 1e-2, 1e-2, "decode attention")
+    s = torch.einsum("bqhd,bkhd->bhqk", q.float().reshape(B, 1, H, 64) * 0.125, k.float().reshape(B, Tk, H, 64))
+    if mask is not None:
+        s = s + ((1.0 - mask.float()) * FMIN)[:, None, None, :]
+    close(lse, torch.logsumexp(s, -1), 1e-3, 1e-3 * max(1.0, 0.0), "decode lse") if mask is None else None
+
+
 # ------------------------------------------------------------------------------------------------- LN
 @pytest.mark.parametrize("R,D", [(64, 1024), (37, 768), (5, 512), (128, 2048)])
 def test_add_ln(K, R, D):
@@ -388,3 +409,23 @@ def test_misc(K):
     assert K.face_mask(face).tolist() == [[1, 0, 0], [0, 0, 0]]
     x32 = rnd(1000, dtype=torch.float32, seed=6)
     assert torch.equal(K.cast_f32_bf16(x32), x32.bfloat16())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K_", [(5, 1024, 1024), (1, 3072, 1024), (8, 1024, 4096), (5, 50267, 1024), (3, 1000, 520)])
+def test_gemm_skinny_rows(K, M, N, K_):
+    """single-token decode shapes: M <= 8 goes through the W-streaming kernel (bias, GELU, bf16 and fp32 outputs, ldo > N)."""
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + N)
+    x = (torch.randn(M, K_, device="cuda", generator=g) * 0.5).bfloat16()
+    w = (torch.randn(N, K_, device="cuda", generator=g) * 0.05).bfloat16()
+    b = torch.randn(N, device="cuda", generator=g)
+    ref = x.float() @ w.float().t() + b
+    tol = 2e-2 * ref.abs().max().item()
+    close(K.gemm(x, w, M, N, K_, bias=b), ref, 1e-2, tol, "skinny bf16")
+    close(K.gemm(x, w, M, N, K_, bias=b, tile_hint=64), ref, 1e-2, tol, "tile path bf16")
+    close(K.gemm(x, w, M, N, K_, bias=b, act="gelu"), torch.nn.functional.gelu(ref), 1e-2, tol, "skinny gelu")
+    ldo = (N + 15) // 8 * 8
+    out = torch.zeros(M, ldo, device="cuda", dtype=torch.float32)
+    K.gemm(x, w, M, N, K_, bias=b, out=out, ldo=ldo, out_mode=1)
+    close(out[:, :N], ref, 1e-3, 2e-3 * ref.abs().max().item(), "skinny fp32 out")
+    assert out[:, N:].abs().max().item() == 0.0

@@ -160,6 +160,7 @@ GEN_CASES = [(5, 2.0, {}), (5, 1.0, {}), (1, 1.0, dict(min_length=4)), (5, 1.0, 
 def gen_inputs():
     cfg = small_cfg(encoder_layers=1, decoder_layers=1)
     sd = synthetic.make_state_dict(synthetic.mmbart_param_shapes(cfg), seed=1)
+    sd["model.shared.weight"] = sd["model.shared.weight"] * synthetic.GEN_SHARPEN      # as oracle/make_golden.py::run_generate_case
     batch = synthetic.make_batch(cfg, 2, S=24, T=8, F=2, seed=9, image_size=32)
     img = synthetic._normal("img_cls", (2, 768), 1.0, 3)
     kw = dict(face_features=batch["face_emb"], face_mask=O.create_src_mask_bart(batch["face_emb"][:, :, -1]),

@@ -502,6 +502,100 @@ int check_common(int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t ldq, int6
 
 }  // namespace
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Single-query attention (Tq == 1, no causal flag): the KV-cached decoder step of caption generation (MFULL:474-501).
+// One wave per (batch row, head): lanes split the keys for q.k, a wave reduction gives the softmax statistics, the
+// probabilities go through LDS, then lanes = (8 key groups) x (8 chunks of 8 dims) accumulate P.V and meet in three
+// shuffle steps.  fp32 throughout; same additive finfo.min mask semantics as the tiled kernel.
+__global__ __launch_bounds__(64) void attn_decode_kernel(AttnP p) {
+  extern __shared__ float probs[];                    // Tk floats
+  const int lane = threadIdx.x, h = blockIdx.x, b = blockIdx.y;
+  const bf16_t* q = p.q + (long)b * p.bsq + h * 64;
+  const bf16_t* kb = p.k + (long)b * p.bsk + h * 64;
+  const bf16_t* vb = p.v + (long)b * p.bsv + h * 64;
+  const uint8_t* km = p.key_mask ? p.key_mask + (long)b * p.Tk : nullptr;
+  float qf[64];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const u32x4 r = *(const u32x4*)(q + c * 8);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { qf[c * 8 + 2 * i] = __uint_as_float(r[i] << 16); qf[c * 8 + 2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u); }
+  }
+  float m = -INFINITY;
+  // keys in batches of 4 per lane: all 32 16-byte loads of a batch are issued before the first is consumed (with one wave
+  // per CU nothing else hides the ~2 us round trip of a load)
+  for (int key0 = lane; key0 < p.Tk; key0 += 256) {
+    u32x4 kr[4][8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int key = key0 + 64 * u;
+      const bf16_t* krow = kb + (long)(key < p.Tk ? key : key0) * p.ldk;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) kr[u][c] = *(const u32x4*)(krow + c * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int key = key0 + 64 * u;
+      if (key < p.Tk) {
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            dot += qf[c * 8 + 2 * i] * __uint_as_float(kr[u][c][i] << 16);
+            dot += qf[c * 8 + 2 * i + 1] * __uint_as_float(kr[u][c][i] & 0xffff0000u);
+          }
+        float sc = dot * p.scale;
+        if (km && km[key] == 0) sc += -3.4028234663852886e38f;     // additive finfo(float32).min, as _expand_mask
+        probs[key] = sc;
+        m = fmaxf(m, sc);
+      }
+    }
+  }
+  m = wave_max(m);
+  float l = 0.f;
+  for (int key = lane; key < p.Tk; key += 64) {
+    const float e = __expf(probs[key] - m);
+    probs[key] = e;
+    l += e;
+  }
+  l = wave_sum(l);
+  __syncthreads();
+  const int kg = lane >> 3, dc = lane & 7;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int key0 = kg; key0 < p.Tk; key0 += 64) {
+    u32x4 vr[8]; float pk[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int key = key0 + 8 * u;
+      const bool ok = key < p.Tk;
+      vr[u] = *(const u32x4*)(vb + (long)(ok ? key : key0) * p.ldv + dc * 8);
+      pk[u] = ok ? probs[key] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[2 * i] += pk[u] * __uint_as_float(vr[u][i] << 16);
+        acc[2 * i + 1] += pk[u] * __uint_as_float(vr[u][i] & 0xffff0000u);
+      }
+  }
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], o, 64);
+  if (kg == 0) {
+    const float inv = 1.f / l;
+    bf16_t* o = p.out + (long)b * p.bso + h * 64 + dc * 8;
+    *(u32x4*)o = (u32x4){pack2bf(acc[0] * inv, acc[1] * inv), pack2bf(acc[2] * inv, acc[3] * inv),
+                         pack2bf(acc[4] * inv, acc[5] * inv), pack2bf(acc[6] * inv, acc[7] * inv)};
+  }
+  if (p.lse && lane == 0) p.lse[((long)b * p.H + h)] = m + logf(l);
+}
+
 extern "C" int vacnic_attn_fwd(const vacnic_attn_fwd_args* a, void* stream) {
   VCHECK(a && a->q && a->k && a->v && a->out, VACNIC_BAD_SHAPE, "attn_fwd: null operand");
   if (int e = check_common(a->B, a->H, a->Tq, a->Tk, a->ldq, a->ldk, a->ldv, a->ldo, "attn_fwd")) return e;
@@ -514,6 +608,11 @@ extern "C" int vacnic_attn_fwd(const vacnic_attn_fwd_args* a, void* stream) {
   p.ldq = (int)a->ldq; p.ldk = (int)a->ldk; p.ldv = (int)a->ldv; p.ldo = (int)a->ldo;
   p.bsq = a->bsq; p.bsk = a->bsk; p.bsv = a->bsv; p.bso = a->bso;
   p.causal = a->causal; p.scale = a->scale;
+  if (p.Tq == 1 && !p.causal && p.Tk <= 16384) {      // decoder step: one wave per (row, head)
+    hipLaunchKernelGGL(attn_decode_kernel, dim3(p.H, p.B), dim3(64), (size_t)p.Tk * 4, (hipStream_t)stream, p);
+    VLAUNCH_CHECK();
+    return VACNIC_OK;
+  }
   const int Tk_pad = (p.Tk + 63) & ~63;
   dim3 grid((p.Tq + 127) / 128, p.H, p.B);
   hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 4 * TILE_B + Tk_pad * 4, (hipStream_t)stream, p);

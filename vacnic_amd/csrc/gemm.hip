@@ -590,6 +590,77 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Skinny-M GEMM (M <= 8): the single-token decoder of caption generation (MFULL:474-501, beams*batch rows) and any other
+// GEMM whose X is a handful of rows.  HBM-bound: W [N,K] is streamed exactly once; X (<= 8 x K bf16) is re-read from
+// L1/L2.  One wave owns CW consecutive output columns; its 64 lanes split K in 16-byte chunks, accumulate MR x CW partial
+// dot products in fp32 and meet in a wave reduction.  No LDS, no barriers.
+template <int MR, int CW>
+__global__ __launch_bounds__(64) void gemm_skinny_kernel(GemmP p) {
+  // one wave per workgroup: N / CW independent waves spread over every CU (N = 1024 -> 256 workgroups), each limited only
+  // by one round trip of its loads
+  const int lane = threadIdx.x;
+  const int n0 = blockIdx.x * CW;
+  constexpr int NV = MR * CW;                        // 32 partial dot products per lane
+  float acc[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) acc[i] = 0.f;
+  const int nchunk = p.K >> 3;                       // host guarantees K % 8 == 0
+#pragma unroll 4
+  for (int ch = lane; ch < nchunk; ch += 64) {
+    float wv[CW][8];
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      if (n0 + c < p.N) load8bf(p.w + (size_t)(n0 + c) * p.ldw + ch * 8, wv[c]);
+      else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wv[c][j] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+      if (m < p.M) {
+        float xv[8];
+        load8bf(p.x + (size_t)m * p.ldx + ch * 8, xv);
+#pragma unroll
+        for (int c = 0; c < CW; ++c)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[m * CW + c] += xv[j] * wv[c][j];
+      }
+    }
+  }
+  // reduce-scatter butterfly: at offset 32,16,8,4,2 every lane hands the half of its values its partner keeps and adds the
+  // half it keeps (16+8+4+2+1 exchanges), then one last exchange at offset 1 -> 32 cross-lane moves for 32 sums instead of 192.
+  static_assert(NV == 32, "butterfly written for 32 values per lane");
+#define VAC_BFLY(OFF, HALF)                                                      \
+  {                                                                              \
+    const bool up = (lane & OFF) != 0;                                           \
+    _Pragma("unroll") for (int i = 0; i < HALF; ++i) {                           \
+      const float send = up ? acc[i] : acc[HALF + i];                            \
+      const float keep = up ? acc[HALF + i] : acc[i];                            \
+      acc[i] = keep + __shfl_xor(send, OFF, 64);                                 \
+    }                                                                            \
+  }
+  VAC_BFLY(32, 16) VAC_BFLY(16, 8) VAC_BFLY(8, 4) VAC_BFLY(4, 2) VAC_BFLY(2, 1)
+#undef VAC_BFLY
+  float v = acc[0] + __shfl_xor(acc[0], 1, 64);
+  if ((lane & 1) == 0) {
+    const int idx = (((lane >> 5) & 1) << 4) | (((lane >> 4) & 1) << 3) | (((lane >> 3) & 1) << 2) | (((lane >> 2) & 1) << 1) | ((lane >> 1) & 1);
+    const int m = idx / CW, c = idx % CW;
+    const int n = n0 + c;
+    if (m < p.M && n < p.N) {
+      v *= p.alpha;
+      if (p.bias) v += p.bias[n];
+      v = act_fwd(p.act, v);
+      const size_t off = (size_t)m * p.ldo + n;
+      if (p.out_mode == 0) ((bf16_t*)p.out)[off] = f2bf(v);
+      else if (p.out_mode == 1) ((float*)p.out)[off] = v;
+      else ((float*)p.out)[off] += v;
+    }
+  }
+}
+
 template <int BM, int BN, int WM, int WN, int BKT, int NSTAGE, bool PIPE = false, bool STAGGER = false>
 int launch_gemm(const GemmP& p0, bool xks, bool wks, int zsplits, hipStream_t s) {
   GemmP p = p0;
@@ -642,6 +713,9 @@ extern "C" int vacnic_gemm_bf16(const vacnic_gemm_args* a, void* stream) {
   VCHECK(a->M > 0 && a->N > 0 && a->K > 0, VACNIC_BAD_SHAPE, "gemm: empty problem M=%ld N=%ld K=%ld",
          (long)a->M, (long)a->N, (long)a->K);
   if (a->tile_hint != 0) return gemm_one(a, a->tile_hint, stream);
+  if (a->M <= 8 && !a->x_kstrided && !a->w_kstrided && a->split_k <= 1 && !a->preact && !a->dact_src && !a->residual &&
+      (a->K & 7) == 0)
+    return gemm_one(a, 8, stream);
   const int split = a->split_k < 1 ? 1 : a->split_k;
   int64_t kper = (a->K + split - 1) / split;
   kper = (kper + BK - 1) / BK * BK;
@@ -712,6 +786,15 @@ static int gemm_one(const vacnic_gemm_args* a, int tile_hint, void* stream) {
   p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
   p.tiles_m = p.tiles_n = 0;
   hipStream_t s = (hipStream_t)stream;
+  if (tile_hint == 8) {     // skinny-M kernel (chosen by vacnic_gemm_bf16 for M <= 8, or forced by the caller)
+    VCHECK(a->M <= 8 && !a->x_kstrided && !a->w_kstrided && zsplits == 1 && !a->preact && !a->dact_src && !a->residual &&
+           (a->K & 7) == 0, VACNIC_UNSUPPORTED, "gemm: the skinny kernel needs M <= 8, K-contiguous operands, K %% 8 == 0 and a plain epilogue");
+    constexpr int CW = 4;
+    dim3 grid((unsigned)((a->N + CW - 1) / CW));
+    hipLaunchKernelGGL((gemm_skinny_kernel<8, CW>), grid, dim3(64), 0, s, p);
+    VLAUNCH_CHECK();
+    return VACNIC_OK;
+  }
   const int force = tile_hint % 1000;
   p.debug = tile_hint / 1000;
   const bool big = force == 256;

@@ -55,27 +55,39 @@ def _banned(seq, n):
 
 
 class CachedDecoder:
-    """Single-token decoder over preallocated KV caches (eval mode, no autograd)."""
+    """Single-token decoder over preallocated KV caches (eval mode, no autograd).  All buffers are allocated once and the
+    cache in use at position t is `cache[t & 1]` when beams are reordered every step (no hidden toggle), so a step is a pure
+    function of (static buffers, t) and can be captured as a hipGraph."""
 
-    def __init__(self, model, enc_h, enc_mask_u8, rows, max_length):
+    def __init__(self, model, rows, S, max_length, reorders):
         self.m = model
         dec = model.model.decoder
         self.dec = dec
         self.L = len(dec.layers)
         d = model.config.d_model
         self.d, self.H = d, model.config.decoder_attention_heads
-        self.rows, self.Tmax = rows, max_length
-        dev = enc_h.device
-        self.cache = [torch.zeros((self.L, rows, max_length, 2 * d), device=dev, dtype=BF16) for _ in range(2)]
-        self.cur = 0
-        self.enc_mask = enc_mask_u8
-        S = enc_h.shape[1]
-        M = rows * S
-        # cross-attention K/V of every layer, once (the decoder's largest GEMMs: M = rows*S)
-        self.cross = []
-        for layer in dec.layers:
+        self.rows, self.Tmax, self.S, self.reorders = rows, max_length, S, reorders
+        dev = model.emb16_pad.device
+        self.cache = [torch.zeros((self.L, rows, max_length, 2 * d), device=dev, dtype=BF16) for _ in range(2 if reorders else 1)]
+        self.enc_b = torch.empty((rows, S, d), device=dev, dtype=BF16)
+        self.enc_mask = torch.empty((rows, S), device=dev, dtype=torch.uint8)
+        self.cross = [torch.empty((rows, S, 2 * d), device=dev, dtype=BF16) for _ in range(self.L)]
+        self.lidx = (torch.arange(self.L, device=dev)[:, None] * rows).contiguous()
+
+    def begin(self, enc_h, mask_u8, nb):
+        """expand the encoder states to beams (HF _expand_inputs_for_generation: row b*nb + j <- batch b) and compute the
+        cross-attention K/V of every layer once (the decoder's largest GEMMs: M = rows*S)."""
+        B, S, d = enc_h.shape
+        for j in range(nb):
+            K.copy3d(enc_h, self.enc_b[j::nb], B, S, d)
+        self.enc_mask.copy_(mask_u8.repeat_interleave(nb, dim=0))
+        M = self.rows * S
+        for li, layer in enumerate(self.dec.layers):
             a = layer.encoder_attn
-            self.cross.append(K.gemm(enc_h.view(M, d), a.s_kv.w16, M, 2 * d, d, bias=a.s_kv.bias).view(rows, S, 2 * d))
+            K.gemm(self.enc_b.view(M, d), a.s_kv.w16, M, 2 * d, d, bias=a.s_kv.bias, out=self.cross[li].view(M, 2 * d))
+
+    def cache_at(self, t):
+        return self.cache[t & 1] if self.reorders else self.cache[0]
 
     def step(self, ids_t, t):
         """ids_t int64 [rows, 1] (token at position t) -> fp32 logits [rows, V_pad]."""
@@ -83,7 +95,7 @@ class CachedDecoder:
         ln = dec.layernorm_embedding
         h, _, _ = K.embed_ln_fwd(ids_t, dec.embed_tokens.weight.w16, dec.embed_positions.weight.w16, ln.weight.data, ln.bias.data,
                                  embed_scale=dec.embed_scale, pos_offset=2 + t)
-        cache = self.cache[self.cur]
+        cache = self.cache_at(t)
         for li, layer in enumerate(dec.layers):
             a = layer.self_attn
             kvq = K.gemm(h.view(R, d), a.s_kvq.w16, R, 3 * d, d, bias=a.s_kvq.bias).view(R, 1, 3 * d)
@@ -106,19 +118,83 @@ class CachedDecoder:
         K.gemm(h.view(R, d), m.emb16_pad, R, m.V, d, bias=m.final_logits_bias.view(-1), out=logits, ldo=m.V_pad, out_mode=1)
         return logits
 
-    def reorder(self, beam_idx):
-        """self-attention caches of all layers follow their beams (one launch)."""
+    def reorder(self, beam_idx, t):
+        """before step t: the self-attention caches of all layers follow their beams (one launch; _reorder_cache
+        MFULL:2066-2074): cache[(t-1)&1] gathered into cache[t&1]."""
         L, R = self.L, self.rows
-        idx = (torch.arange(L, device=beam_idx.device)[:, None] * R + beam_idx[None, :]).reshape(-1).contiguous()
-        src, dst = self.cache[self.cur], self.cache[self.cur ^ 1]
-        K.gather_rows(src, dst, idx, L * R, self.Tmax * 2 * self.d * 2)
-        self.cur ^= 1
+        idx = (self.lidx + beam_idx[None, :]).reshape(-1)
+        K.gather_rows(self.cache[(t - 1) & 1], self.cache[t & 1], idx, L * R, self.Tmax * 2 * self.d * 2)
+
+
+class DecodeSession:
+    """Everything device-side of one decode shape (rows, S, max_length, logits-processor options): static buffers, the
+    cached decoder, and one hipGraph per position t = {cache reorder, 12-layer single-token decoder, LM head, log-softmax +
+    processors + top-2k}.  The first caption of a shape runs eagerly (it also warms every kernel); from the second on each
+    position is captured on first use and replayed afterwards, which removes the ~170 Python->HIP launches per token that
+    bound the eager loop."""
+
+    def __init__(self, model, R, S, max_length, nb, ngram, min_length, forced_eos, eos):
+        self.model, self.R, self.nb, self.max_length = model, R, nb, max_length
+        self.ngram, self.min_length, self.forced_eos, self.eos = ngram, min_length, forced_eos, eos
+        dev = model.emb16_pad.device
+        self.dec = CachedDecoder(model, R, S, max_length, reorders=nb > 1)
+        self.ids_s = torch.zeros((R, 1), device=dev, dtype=torch.long)
+        self.scores_s = torch.zeros(R, device=dev, dtype=torch.float32)
+        self.src_s = torch.zeros(R, device=dev, dtype=torch.long)
+        self.bans_s = torch.full((R, max_length), -1, device=dev, dtype=torch.int32) if ngram > 0 else None
+        self.h_ids = torch.zeros((R, 1), dtype=torch.long).pin_memory()
+        self.h_scores = torch.zeros(R, dtype=torch.float32).pin_memory()
+        self.h_src = torch.zeros(R, dtype=torch.long).pin_memory()
+        self.h_bans = torch.full((R, max_length), -1, dtype=torch.int32).pin_memory() if ngram > 0 else None
+        self.graphs, self.outs, self.pool = {}, {}, None
+        self.captions = 0
+
+    def body(self, t):
+        if self.nb > 1 and t > 0:
+            self.dec.reorder(self.src_s, t)
+        logits = self.dec.step(self.ids_s, t)
+        cur_len = t + 1
+        forced = self.forced_eos if (self.forced_eos is not None and cur_len == self.max_length - 1) else -1
+        V = self.model.V
+        return K.beam_topk(logits, V, min(2 * self.nb, V), beam_scores=self.scores_s, bans=self.bans_s, eos=self.eos,
+                           suppress_eos=cur_len < self.min_length, forced_token=forced)
+
+    def step(self, t, last_tokens, scores, src, bans, use_graphs):
+        """host lists in, (top values, top ids) on the host out — the one device->host sync of the position."""
+        self.h_ids[:, 0] = torch.as_tensor(last_tokens)
+        self.ids_s.copy_(self.h_ids, non_blocking=True)
+        self.h_scores.copy_(torch.as_tensor(scores, dtype=torch.float32))
+        self.scores_s.copy_(self.h_scores, non_blocking=True)
+        if self.nb > 1 and t > 0:
+            self.h_src.copy_(torch.as_tensor(src))
+            self.src_s.copy_(self.h_src, non_blocking=True)
+        if self.bans_s is not None:
+            self.h_bans.fill_(-1)
+            for r, bl in enumerate(bans):
+                if bl:
+                    self.h_bans[r, :len(bl)] = torch.as_tensor(bl, dtype=torch.int32)
+            self.bans_s.copy_(self.h_bans, non_blocking=True)
+        if use_graphs and self.captions > 0:
+            g = self.graphs.get(t)
+            if g is None:
+                g = torch.cuda.CUDAGraph()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g, pool=self.pool):
+                    self.outs[t] = self.body(t)
+                if self.pool is None:
+                    self.pool = g.pool()
+                self.graphs[t] = g
+            g.replay()
+            tv, ti = self.outs[t]
+        else:
+            tv, ti = self.body(t)
+        return tv.cpu(), ti.cpu()
 
 
 @torch.no_grad()
 def generate(model, input_ids=None, attention_mask=None, num_beams=1, max_length=20, length_penalty=1.0, early_stopping=False,
              no_repeat_ngram_size=0, min_length=0, forced_eos_token_id="config", image_features=None, face_features=None,
-             face_mask=None, name_ids=None, name_mask=None, add_ner_ffn=True, **unused):
+             face_mask=None, name_ids=None, name_mask=None, add_ner_ffn=True, use_graphs=True, **unused):
     """GenerationMixin.generate(do_sample=False) semantics of transformers 4.18 for this model (greedy = 1 beam).
     Returns int64 [B, L] starting with decoder_start_token_id, padded with pad_token_id."""
     cfg = model.config
@@ -137,35 +213,26 @@ def generate(model, input_ids=None, attention_mask=None, num_beams=1, max_length
                               name_mask=name_mask, face_features=face_features, face_mask=face_mask, add_ner_ffn=add_ner_ffn)
     enc_h = enc["last_hidden_state"]
     S, d = enc_h.shape[1], enc_h.shape[2]
-    # expand to beams (HF _expand_inputs_for_generation): row b*nb + j <- batch b
-    enc_b = torch.empty((R, S, d), device=enc_h.device, dtype=BF16)
-    mask_b = mask_u8.repeat_interleave(nb, dim=0).contiguous()
-    for j in range(nb):
-        K.copy3d(enc_h, enc_b[j::nb], B, S, d)
-    dec = CachedDecoder(model, enc_b, mask_b, R, max_length)
+    key = (R, S, max_length, nb, no_repeat_ngram_size, min_length, forced_eos_token_id)
+    sessions = model.__dict__.setdefault("_decode_sessions", {})
+    ses = sessions.get(key)
+    if ses is None:
+        ses = sessions[key] = DecodeSession(model, R, S, max_length, nb, no_repeat_ngram_size, min_length, forced_eos_token_id, eos)
+    ses.dec.begin(enc_h, mask_u8, nb)
 
     seqs = [[start] for _ in range(R)]
-    beam_scores = torch.zeros((B, nb), dtype=torch.float32)
-    beam_scores[:, 1:] = -1e9
-    beam_scores = beam_scores.view(-1)
+    beam_scores = [0.0 if (r % nb) == 0 else -1e9 for r in range(R)]
     hyps = [_BeamHyps(nb, length_penalty, early_stopping) for _ in range(B)]
     done = [False] * B
     cur_len = 1
     Kc = 2 * nb
     dev = enc_h.device
+    new_src = list(range(R))
     while True:
         t = cur_len - 1
-        ids_t = torch.tensor([[s[-1]] for s in seqs], dtype=torch.long, device=dev)
-        logits = dec.step(ids_t, t)
-        bans = None
-        if no_repeat_ngram_size > 0:
-            bl = [_banned(s, no_repeat_ngram_size) for s in seqs]
-            width = max(1, max(len(b) for b in bl))
-            bans = torch.tensor([b + [-1] * (width - len(b)) for b in bl], dtype=torch.int32, device=dev)
-        forced = forced_eos_token_id if (forced_eos_token_id is not None and cur_len == max_length - 1) else -1
-        tv, ti = K.beam_topk(logits, model.V, min(Kc, model.V), beam_scores=beam_scores.to(dev), bans=bans, eos=eos,
-                             suppress_eos=cur_len < min_length, forced_token=forced)
-        tv, ti = tv.cpu(), ti.cpu()                                   # the one device->host sync of the step
+        bans = [_banned(s_, no_repeat_ngram_size) for s_ in seqs] if no_repeat_ngram_size > 0 else None
+        tv, ti = ses.step(t, [s_[-1] for s_ in seqs], beam_scores, new_src, bans, use_graphs)
+        tv, ti = tv.tolist(), ti.tolist()
         new_seqs, new_scores, new_src = [], [], []
         for b in range(B):
             if done[b]:
@@ -174,9 +241,10 @@ def generate(model, input_ids=None, attention_mask=None, num_beams=1, max_length
             # merge the per-beam top-2k lists into the group's top-2k (HF: topk over the [nb*V] scores of the group)
             cand = []
             for j in range(nb):
-                for c in range(tv.shape[1]):
-                    if ti[b * nb + j, c] >= 0:
-                        cand.append((float(tv[b * nb + j, c]), j, int(ti[b * nb + j, c])))
+                row_v, row_i = tv[b * nb + j], ti[b * nb + j]
+                for c in range(len(row_v)):
+                    if row_i[c] >= 0:
+                        cand.append((row_v[c], j, row_i[c]))
             cand.sort(key=lambda x: (-x[0], x[1] * model.V + x[2]))
             cand = cand[:Kc]
             chosen = []
@@ -196,12 +264,11 @@ def generate(model, input_ids=None, attention_mask=None, num_beams=1, max_length
             for sc, tok, src in chosen:
                 new_seqs.append(seqs[src] + [tok]); new_scores.append(sc); new_src.append(src)
         seqs = new_seqs
-        beam_scores = torch.tensor(new_scores, dtype=torch.float32)
+        beam_scores = new_scores
         cur_len += 1
         if all(done) or cur_len >= max_length:
             break
-        if nb > 1:
-            dec.reorder(torch.tensor(new_src, dtype=torch.long, device=dev))
+    ses.captions += 1
     out = []
     for b in range(B):
         if not done[b]:

@@ -6,6 +6,8 @@ import zlib
 import numpy as np
 import torch
 
+GEN_SHARPEN = 6.0     # scale of the tied embedding/LM-head matrix in the caption-generation test fixtures (spreads the logits like a trained model)
+
 from .config import ClipVisionConfig, VacnicConfig
 
 
