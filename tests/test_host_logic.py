@@ -129,3 +129,46 @@ def test_resize_token_embeddings_keeps_tie():
     assert m.model.shared.weight.shape[0] == 50267 and m.lm_head.weight is m.model.shared.weight
     assert m.model.encoder.embed_tokens is m.model.shared and m.final_logits_bias.shape == (1, 50267)
     assert torch.equal(m.model.shared.weight[:50265], old)
+
+
+def test_checkpoint_round_trip_reference_names_on_host():
+    """a checkpoint is keyed by the reference's parameter names and restores weights, AdamW moments, the
+    LR-schedule position and the dropout RNG (host arenas; the GPU resume equivalence is tests/test_model_gpu.py)."""
+    import io
+    from vacnic_amd import checkpoint, ops, synthetic
+    from vacnic_amd.models.mmbart import BartForMultiModalGeneration
+    from vacnic_amd.training import FusedAdamW
+    cfg = small_cfg(encoder_layers=1, decoder_layers=1)
+
+    def make(seed):
+        torch.manual_seed(seed)
+        m = BartForMultiModalGeneration(cfg, enc_fusion_layer=[0], dim_common=768, prompt_size=cfg.prompt_size).finalize("cpu")
+        o = FusedAdamW(m.arena, lr=3e-5, num_warmup_steps=5, num_training_steps=100)
+        return m, o
+    m1, o1 = make(1)
+    o1.arena.exp_avg.normal_(); o1.arena.exp_avg_sq.uniform_(); o1.hyper.copy_(torch.tensor([1.25e-5, 7.0]))
+    ops.Rng.manual_seed(99); ops.Rng.counter = 1234
+    buf = io.BytesIO()
+    ck = checkpoint.save_checkpoint(buf, m1, o1, step=7, note="t")
+    want = set(synthetic.mmbart_param_shapes(cfg)) | {"model.encoder.embed_tokens.weight", "model.decoder.embed_tokens.weight",
+                                                     "lm_head.weight", "final_logits_bias"}
+    assert set(ck["model"]) == want, set(ck["model"]) ^ want
+    assert set(ck["optimizer"]["exp_avg"]) == set(synthetic.mmbart_param_shapes(cfg))
+    assert all(ck["optimizer"]["exp_avg"][k].shape == ck["model"][k].shape for k in ck["optimizer"]["exp_avg"])
+    m2, o2 = make(2)
+    ops.Rng.manual_seed(0)
+    buf.seek(0)
+    meta = checkpoint.load_checkpoint(buf, m2, o2)
+    assert meta["step"] == 7 and meta["note"] == "t"
+    for (k, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert torch.equal(p, q), k
+    assert torch.equal(m2.arena.flat16, m1.arena.flat16)                      # bf16 shadow refreshed
+    # moments equal wherever a parameter lives (arena padding stays zero)
+    for p, q in zip(m1.arena.params, m2.arena.params):
+        o, n, _ = m1.arena.slots[id(p)]; o2_, _, _ = m2.arena.slots[id(q)]
+        assert torch.equal(o1.arena.exp_avg[o:o + n], o2.arena.exp_avg[o2_:o2_ + n])
+        assert torch.equal(o1.arena.exp_avg_sq[o:o + n], o2.arena.exp_avg_sq[o2_:o2_ + n])
+    assert torch.equal(o2.hyper, o1.hyper) and ops.Rng.base == 99 and ops.Rng.counter == 1234
+    with pytest.raises(KeyError):
+        bad = dict(ck, model={k: v for k, v in ck["model"].items() if k != "lm_head.weight"})
+        checkpoint.load_checkpoint(bad, m2, o2)

@@ -212,6 +212,40 @@ def test_train_steps_reduce_loss_and_match_oracle_adamw():
     assert (pad == 0).all(), "padded embedding rows stay exactly zero"
 
 
+def test_checkpoint_resume_continues_the_run():
+    """save after 2 steps, keep training 3 more; a differently-initialised model + optimizer restored from the
+    checkpoint must continue with the same losses (weights, AdamW moments, LR position and dropout RNG all restored;
+    tolerance covers only the order of the split-K / LayerNorm fp32 atomics)."""
+    import io
+    from vacnic_amd import checkpoint, ops, synthetic, streams
+    from vacnic_amd.config import ClipVisionConfig
+    from vacnic_amd.training import FusedAdamW, TrainArgs, build_models, to_device, train_step
+    cfg = small_cfg(dropout=0.1, encoder_layers=1, decoder_layers=1)
+    vcfg = ClipVisionConfig(width=768, layers=1, patch_size=16, image_size=32, output_dim=64)
+    args = TrainArgs(num_training_steps=20, warmup_rate=0.1, lr_bart=1e-4)
+    batches = [to_device(synthetic.make_batch(cfg, 3, S=32, T=12, F=3, seed=20 + i, image_size=32), "cuda") for i in range(5)]
+    streams.enable(False)
+    ops.Rng.manual_seed(7)
+    ops.Rng.device_counter().zero_()
+    model, guide, _ = build_models(cfg, vcfg, init="synthetic", seed=0)
+    opt = FusedAdamW(model.arena, lr=args.lr_bart, weight_decay=args.weight_decay, num_warmup_steps=2, num_training_steps=20)
+    for i in range(2):
+        train_step(model, guide, opt, batches[i], args)
+    buf = io.BytesIO()
+    checkpoint.save_checkpoint(buf, model, opt, step=2)
+    want = [train_step(model, guide, opt, batches[i], args).tolist() for i in range(2, 5)]
+    model2, _, _ = build_models(cfg, vcfg, init="synthetic", seed=5)          # different weights before the restore
+    model2.clip_model = model.clip_model                                       # the frozen CLIP tower is not part of a checkpoint (TRAIN:737-739 loads it separately)
+    opt2 = FusedAdamW(model2.arena, lr=args.lr_bart, weight_decay=args.weight_decay, num_warmup_steps=2, num_training_steps=20)
+    ops.Rng.manual_seed(123)
+    buf.seek(0)
+    meta = checkpoint.load_checkpoint(buf, model2, opt2)
+    assert meta["step"] == 2 and opt2.hyper[1].item() == 2.0
+    got = [train_step(model2, guide, opt2, batches[i], args).tolist() for i in range(2, 5)]
+    np.testing.assert_allclose(np.array(got), np.array(want), rtol=2e-4, atol=1e-5)
+    assert abs(opt2.hyper[0].item() - opt.hyper[0].item()) < 1e-12
+
+
 def test_greedy_decode_ids_match_oracle():
     from oracle import vacnic_oracle as O
     from vacnic_amd import kernels as K, synthetic
@@ -362,3 +396,26 @@ def test_cfg4_long_article_1024_tokens_step_and_oracle():
     hist = [train_step(model, guide, opt, b4, TrainArgs(num_training_steps=100)).tolist() for _ in range(4)]
     assert all(np.isfinite(h).all() for h in hist), hist
     assert hist[-1][1] < hist[0][1], hist
+
+
+def test_trainer_entry_point_runs_and_resumes(tmp_path):
+    """the reference-named trainer script, its flag surface and --resume (child processes, like torchrun would start it)."""
+    import json
+    import subprocess
+    import sys
+    script = os.path.join(ROOT, "train_mmbart_enc_self_face_name_ids_retrieve_crossattn_bart_guide_match.py")
+    common = [sys.executable, script, "--plm_type", "facebook/bart-base", "--clip_type", "ViT-B/32", "--enc_fusion_layer", "0", "1",
+              "--dim_common", "768", "--train_batch_size", "2", "--article_max_length", "64", "--steps_per_epoch", "3", "--log_every", "1",
+              "--use_secla", "True", "--margin", "1.0", "--alpha", "0.5", "--no_clip_norm", "True", "--out_dir", str(tmp_path),
+              "--experiment_name", "t"]
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    r1 = subprocess.run(common + ["--num_epoch", "1"], capture_output=True, text=True, timeout=600, env=env)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    recs1 = [json.loads(l) for l in r1.stdout.splitlines() if l.startswith("{")]
+    assert [r["step"] for r in recs1] == [1, 2, 3] and all(np.isfinite(r["loss"]) for r in recs1)
+    ck = os.path.join(str(tmp_path), "tlast.pt")
+    assert os.path.exists(ck)
+    r2 = subprocess.run(common + ["--num_epoch", "2", "--resume", ck], capture_output=True, text=True, timeout=600, env=env)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    recs2 = [json.loads(l) for l in r2.stdout.splitlines() if l.startswith("{")]
+    assert [r["step"] for r in recs2] == [4, 5, 6], recs2

@@ -74,6 +74,8 @@ parser.add_argument("--alpha", type=float, default=0.5)
 # additions for the synthetic driver
 parser.add_argument("--steps_per_epoch", type=int, default=20)
 parser.add_argument("--log_every", type=int, default=5)
+parser.add_argument("--resume", type=str, default="", help="checkpoint written by a previous run (<out_dir>/<experiment_name>last.pt): "
+                    "weights, AdamW moments, LR-schedule position and dropout RNG are restored and the step count continues")
 
 PLM = {"facebook/bart-base": dict(d_model=768, encoder_layers=6, decoder_layers=6, encoder_attention_heads=12,
                                   decoder_attention_heads=12, encoder_ffn_dim=3072, decoder_ffn_dim=3072),
@@ -116,24 +118,31 @@ def run(args, batches=None):
     opt = FusedAdamW(model.arena, lr=args.lr_bart, weight_decay=args.weight_decay, num_warmup_steps=args.warmup_rate * total_steps,
                      num_training_steps=total_steps, world_size=world)
     step, t0, hist = 0, time.time(), []
-    for epoch in range(int(args.num_epoch)):
+    start_step = 0
+    if args.resume:
+        from vacnic_amd import checkpoint
+        start_step = int(checkpoint.load_checkpoint(args.resume, net, opt)["step"])
+        step = start_step
+    for epoch in range(start_step // args.steps_per_epoch, int(args.num_epoch)):
         it = batches if batches is not None else (
             synthetic.make_batch(cfg, args.train_batch_size, S=args.article_max_length, T=min(64, args.caption_max_length), seed=int(args.seed) % 65536,
                                  rank=rank, step=epoch * args.steps_per_epoch + i) for i in range(args.steps_per_epoch))
-        for batch in it:
+        for bi, batch in enumerate(it):
+            if epoch * args.steps_per_epoch + bi < start_step:
+                continue                                            # already consumed before the checkpoint
             out4 = train_step(net, guide if not args.only_image else None, opt, to_device(batch, "cuda"), targs)
             step += 1
             if step % args.log_every == 0 and rank == 0:          # ONE device->host sync per log interval (the reference does 4 per step)
                 tot, txt, secla, colam = out4.tolist()
                 rec = {"step": step, "loss": tot, "text loss": txt, "face name loss": secla, "margin loss": colam,
-                       "samples_per_s": round(step * args.train_batch_size * world / (time.time() - t0), 2)}
+                       "samples_per_s": round((step - start_step) * args.train_batch_size * world / (time.time() - t0), 2)}
                 hist.append(rec)
                 print(json.dumps(rec), flush=True)
     torch.cuda.synchronize()
     if rank == 0 and args.out_dir:
         os.makedirs(args.out_dir, exist_ok=True)
-        torch.save({k: v.detach().float().cpu() for k, v in model.state_dict().items() if not k.startswith("clip_model")},
-                   os.path.join(args.out_dir, args.experiment_name + "last.pt"))        # state_dict with MFULL names (TRAIN:472 pickles the module)
+        from vacnic_amd import checkpoint          # MFULL-named state_dict + optimizer/schedule/RNG (TRAIN:472 pickles the module object)
+        checkpoint.save_checkpoint(os.path.join(args.out_dir, args.experiment_name + "last.pt"), net, opt, step=step)
     if world > 1:
         dist.destroy_process_group()
     return hist
