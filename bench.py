@@ -161,10 +161,6 @@ def main():
     torch.cuda.set_device(0 if single_dev else local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend)
     from vacnic_amd import synthetic
     from vacnic_amd.config import bart_large_vit_l14
     from vacnic_amd.ddp import DistributedDataParallel
@@ -178,7 +174,6 @@ def main():
     model, guide, _ = build_models(cfg, vcfg, device="cuda", seed=1234, init="device")
     log(f"models ready: {model.arena.n/1e6:.1f}M trainable, {guide.arena.n/1e6:.1f}M guide, {model.clip_model.visual.arena.n/1e6:.1f}M ViT")
     args = TrainArgs(num_training_steps=100000)
-    net = DistributedDataParallel(model) if world > 1 else model
     opt = FusedAdamW(model.arena, lr=args.lr_bart, weight_decay=args.weight_decay,
                      num_warmup_steps=args.warmup_rate * args.num_training_steps, num_training_steps=args.num_training_steps,
                      world_size=world)
@@ -196,6 +191,14 @@ def main():
         except Exception as e:
             log(f"tower graph capture failed ({e!r}); eager launches")
             towers = None
+    # the process group comes up only now: the tower graphs above are captured with no communicator (and no watchdog thread
+    # issuing HIP calls) alive in the process
+    if world > 1:
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    net = DistributedDataParallel(model) if world > 1 else model
     use_graph = world == 1 and a.graph
     log(f"batches resident; warm-up ({'hipGraph capture' if use_graph else 'eager'})")
     graphed = None
