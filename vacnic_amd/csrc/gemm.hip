@@ -495,16 +495,26 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
   const bool vec_ok = (p.ldo & 7) == 0;
   const bool add_bias = blockIdx.z == 0;
   float bia[8];
+  // A pass stages 64 tile rows: RPWM = 64/WM rows from EACH wave row-group, so that every wave deposits in every pass (the
+  // LDS store path has two halves, SIMDs {0,1} and {2,3}; a pass fed by the waves of one wm only ran it at half rate).
+  // LDS row r of pass p holds tile row (r / RPWM) * TM + p * RPWM + r % RPWM.
+  constexpr int RPWM = 64 / WM;
+  static_assert((RPWM % 16 == 0 && TM % RPWM == 0) || BM < 64, "epilogue pass mapping");
+  const bool old_map = (p.debug & 256) != 0;      // A/B: one wave row-group per pass (the previous mapping)
+  auto tile_row = [&](int pass, int r) { return old_map ? pass * 64 + r : (r / RPWM) * TM + pass * RPWM + r % RPWM; };
 #pragma unroll
   for (int pass = 0; pass < PASSES; ++pass) {
-    // every 16-row group of this wave that falls into rows [pass*64, pass*64+64) of the block tile is deposited
 #pragma unroll
     for (int a = 0; a < FA; ++a) {
-      const int row0 = wm * TM + a * 16;
-      if (row0 / 64 == pass) {
+      if (!old_map && (a * 16) / RPWM == pass) {
 #pragma unroll
         for (int b = 0; b < FB; ++b)
-          *(f32x4*)(sc + ((row0 & 63) + lm) * CLD + wn * TN + b * 16 + ln4) = acc[b][a];
+          *(f32x4*)(sc + (wm * RPWM + (a * 16) % RPWM + lm) * CLD + wn * TN + b * 16 + ln4) = acc[b][a];
+      }
+      if (old_map && (wm * TM + a * 16) / 64 == pass) {
+#pragma unroll
+        for (int b = 0; b < FB; ++b)
+          *(f32x4*)(sc + (((wm * TM + a * 16) & 63) + lm) * CLD + wn * TN + b * 16 + ln4) = acc[b][a];
       }
     }
     __syncthreads();
@@ -515,8 +525,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
 #pragma unroll 1
       for (int rr = 0; rr < RPW; ++rr) {
         const int row = wave * RPW + rr;
-        const int m = m0 + pass * 64 + row;
-        if (m >= p.M) break;
+        const int m = m0 + tile_row(pass, row);
+        if (m >= p.M) continue;
 #pragma unroll
         for (int h = 0; h < BN / 64; ++h) {
           const int n = n0 + h * 64 + lane;
@@ -556,7 +566,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
 #pragma unroll
       for (int k = 0; k < RPT; ++k) {
         const int row = rbase + k * RSTEP;
-        const int m = m0 + pass * 64 + row;
+        const int m = m0 + tile_row(pass, row);
         const f32x4 v0 = *(const f32x4*)(sc + row * CLD + c8), v1 = *(const f32x4*)(sc + row * CLD + c8 + 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) { v[k][j] = v0[j]; v[k][4 + j] = v1[j]; }
@@ -569,14 +579,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
       }
 #pragma unroll
       for (int k = 0; k < RPT; ++k) {
-        const int m = m0 + pass * 64 + rbase + k * RSTEP;
+        const int m = m0 + tile_row(pass, rbase + k * RSTEP);
         if (m < p.M) epilogue8_vec(p, v[k], (size_t)m * p.ldo + n, bia, rraw[k], draw[k]);
       }
     } else if (n < p.N) {
 #pragma unroll 1
       for (int k = 0; k < RPT; ++k) {
         const int row = rbase + k * RSTEP;
-        const int m = m0 + pass * 64 + row;
+        const int m = m0 + tile_row(pass, row);
         if (m < p.M) {
           float v[8];
           const f32x4 v0 = *(const f32x4*)(sc + row * CLD + c8), v1 = *(const f32x4*)(sc + row * CLD + c8 + 4);
