@@ -116,7 +116,7 @@ class DistributedDataParallel(torch.nn.Module):
             # side stream (wgrad GEMMs): the collective waits for both
             from . import streams
             self.comm_stream.wait_stream(torch.cuda.current_stream())
-            for s in (streams.wgrad_stream(), torch.cuda.default_stream()):
+            for s in (streams.wgrad_stream(), streams.branch_stream(), torch.cuda.default_stream()):
                 if s is not None:
                     self.comm_stream.wait_stream(s)
             with torch.cuda.stream(self.comm_stream):

@@ -10,11 +10,14 @@ Layout: activations bf16 [B, T, d]; q/k/v of one attention are one fused GEMM ([
 """
 import math
 
+import contextlib
+
 import torch
 from torch import nn
 
 from .. import kernels as K
 from .. import ops
+from .. import streams
 from ..arena import ParamArena
 from ..config import VacnicConfig
 from ..ops import LinearSpec
@@ -147,35 +150,45 @@ class BartEncoderLayer(nn.Module):
                 face_name_key_mask=None, add_ner_ffn=True, fused=True):
         h = hidden_states
         if fused:
-            # img FFN (MFULL:647-653)
-            a, r = ops.fork(hidden_states_img)
-            hidden_states_img = self._ln(ops.mlp2(a, self.fc1.weight, self.s_up, self.s_down), r, self.img_layer_norm)
-            if not self.only_image:
-                if not add_ner_ffn:
-                    raise NotImplementedError("add_ner_ffn=False (non-SECLA contrastive branch, SURVEY §2 row 21)")
-                # face FFN (:658-664)
-                a, r = ops.fork(hidden_states_face)
-                hidden_states_face = self._ln(ops.mlp2(a, self.fc1.weight, self.s_fup, self.s_fdown), r, self.face_layer_norm)
-                face_kv, face_out = ops.fork(hidden_states_face)
-                # names attend to [faces ; names] (:666-679) — no dropout on this branch in the reference
-                ner_q, ner_r = ops.fork(hidden_states_ner)
-                ner_q, ner_k = ops.fork(ner_q)
-                kv_src = ops.cat_tokens(face_kv, ner_k)
-                att = self.self_attn_img_name(ner_q, key_value_states=kv_src, key_mask=face_name_key_mask)
-                hidden_states_ner = self._ln(att, ner_r, self.img_name_attn_layer_norm, drop=False)
-                ner_p, ner_out = ops.fork(hidden_states_ner)
-                # name-prefix FFN on the FLAT view [B, d, N] (reshape, not transpose; :682-688)
-                B, N, d = ner_p.shape
-                pre = ops.mlp2(ner_p.reshape(B, d, N), self.fc1.weight, self.s_nup, self.s_ndown)
-                pre = pre.reshape(B, self.max_ner_type_len_gt, d)
-                pre = ops.add_ln(pre, None, self.ner_map_layer_norm.weight, self.ner_map_layer_norm.bias, self.dropout, self.training)
-                img_kv, img_out = ops.fork(hidden_states_img)
-                kv = ops.cat_tokens(img_kv, pre)                                               # :691
-                hidden_states_img, hidden_states_face, hidden_states_ner = img_out, face_out, ner_out
-            else:
-                kv, hidden_states_img = ops.fork(hidden_states_img)
+            # The image / face / name branches (MFULL:647-691) are a dozen small kernels over 20-80 tokens per sample and are
+            # independent of the text self-attention block of this layer; with side streams on (training only) they run on
+            # the branch stream beside it and join before the cross-attention that consumes their output.
+            br = streams.branch_stream() if (torch.is_grad_enabled() and hidden_states.is_cuda) else None
+            cur = torch.cuda.current_stream() if br is not None else None
+            if br is not None:
+                br.wait_stream(cur)
+            with (torch.cuda.stream(br) if br is not None else contextlib.nullcontext()):
+                # img FFN (MFULL:647-653)
+                a, r = ops.fork(hidden_states_img)
+                hidden_states_img = self._ln(ops.mlp2(a, self.fc1.weight, self.s_up, self.s_down), r, self.img_layer_norm)
+                if not self.only_image:
+                    if not add_ner_ffn:
+                        raise NotImplementedError("add_ner_ffn=False (non-SECLA contrastive branch, SURVEY §2 row 21)")
+                    # face FFN (:658-664)
+                    a, r = ops.fork(hidden_states_face)
+                    hidden_states_face = self._ln(ops.mlp2(a, self.fc1.weight, self.s_fup, self.s_fdown), r, self.face_layer_norm)
+                    face_kv, face_out = ops.fork(hidden_states_face)
+                    # names attend to [faces ; names] (:666-679) — no dropout on this branch in the reference
+                    ner_q, ner_r = ops.fork(hidden_states_ner)
+                    ner_q, ner_k = ops.fork(ner_q)
+                    kv_src = ops.cat_tokens(face_kv, ner_k)
+                    att = self.self_attn_img_name(ner_q, key_value_states=kv_src, key_mask=face_name_key_mask)
+                    hidden_states_ner = self._ln(att, ner_r, self.img_name_attn_layer_norm, drop=False)
+                    ner_p, ner_out = ops.fork(hidden_states_ner)
+                    # name-prefix FFN on the FLAT view [B, d, N] (reshape, not transpose; :682-688)
+                    B, N, d = ner_p.shape
+                    pre = ops.mlp2(ner_p.reshape(B, d, N), self.fc1.weight, self.s_nup, self.s_ndown)
+                    pre = pre.reshape(B, self.max_ner_type_len_gt, d)
+                    pre = ops.add_ln(pre, None, self.ner_map_layer_norm.weight, self.ner_map_layer_norm.bias, self.dropout, self.training)
+                    img_kv, img_out = ops.fork(hidden_states_img)
+                    kv = ops.cat_tokens(img_kv, pre)                                               # :691
+                    hidden_states_img, hidden_states_face, hidden_states_ner = img_out, face_out, ner_out
+                else:
+                    kv, hidden_states_img = ops.fork(hidden_states_img)
             a, r = ops.fork(h)
             h = self._ln(self.self_attn(a, key_mask=key_mask), r, self.self_attn_layer_norm)      # :697-707
+            if br is not None:
+                cur.wait_stream(br)
             a, r = ops.fork(h)
             h = self._ln(self.cross_attn_img_ner(a, key_value_states=kv, key_mask=None), r, self.img_ner_attn_layer_norm)   # :711-723
         else:

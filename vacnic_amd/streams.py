@@ -14,7 +14,7 @@ allocator polls their events on every allocation, which cost ~14 us per torch.em
 """
 import torch
 
-_state = {"enabled": False, "wgrad": None, "aux": None, "vit": None, "wgrad_raw": None, "keep": []}
+_state = {"enabled": False, "wgrad": None, "aux": None, "vit": None, "branch": None, "wgrad_raw": None, "keep": []}
 
 
 def enable(flag=True):
@@ -24,6 +24,7 @@ def enable(flag=True):
         _state["wgrad_raw"] = _state["wgrad"].cuda_stream
         _state["aux"] = torch.cuda.Stream()
         _state["vit"] = torch.cuda.Stream()
+        _state["branch"] = torch.cuda.Stream()
 
 
 def enabled():
@@ -48,6 +49,17 @@ def keep(*tensors):
         k.clear()
 
 
+def branch_stream():
+    """stream of the encoder layer's small-token branches (image / face / name streams of MFULL:647-691: a dozen GEMMs over
+    20-80 tokens per sample that occupy a fraction of the GPU) — they run beside the text self-attention block of the same
+    layer, forward and backward (the autograd engine replays each node on the stream of its forward)."""
+    return _state["branch"] if _state["enabled"] else None
+
+
+def side_streams():
+    return [s for s in (_state["wgrad"], _state["aux"], _state["vit"], _state["branch"]) if s is not None] if _state["enabled"] else []
+
+
 def aux_stream():
     return _state["aux"] if _state["enabled"] else None
 
@@ -63,4 +75,5 @@ def join_all():
         cur.wait_stream(_state["wgrad"])
         cur.wait_stream(_state["aux"])
         cur.wait_stream(_state["vit"])
+        cur.wait_stream(_state["branch"])
         _state["keep"].clear()          # everything the side streams read is now ordered before later compute-stream work
