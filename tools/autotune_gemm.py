@@ -11,7 +11,7 @@ cost model)."""
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-HINTS = (0, 64, 128, 256)
+HINTS = (0, 64, 128, 256, 264)
 REPS = 10
 
 
@@ -52,7 +52,7 @@ def stage_run(path):
         if om == 2:
             splits = [s for s in (1, 2, 4, 8, 16, 32) if Kd // s >= 256 or s == 1]
         for hint in HINTS:
-            if hint == 256 and (M < 256 or N < 256):
+            if hint in (256, 264) and (M < 256 or N < 256):
                 continue
             for sp in splits:
                 sep.add_(1.0)                                  # separator kernel

@@ -303,7 +303,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
     // Ring safety: stage j is read by A in interval 2j and by B in interval 2j+1; MEM(j+1) (intervals 2j+2 / 2j+3) refills
     // its slot with stage j+4.  A wave leaves MEM(h) only when its own pieces of stage h+1 have landed (vmcnt(8): stages
     // h+2, h+3 may fly), and a barrier separates that from every later reader.
-    static_assert(NWAVE == 8 && LOADS == 4, "ping-pong loop is written for the 256x256 / 8-wave configuration");
+    static_assert(NWAVE == 8 && LOADS >= 2, "ping-pong loop is written for 8 waves (two per SIMD)");
     // DMA placement (STAGGER template flag reused as the switch): false = all four pieces in MEM(h); true = the X pieces in
     // MEM(h), the W pieces in the middle of COMP(h) — MEM carries 12 ds_reads + its wait already, and a phase pair is as long
     // as its longer half.
@@ -814,6 +814,7 @@ static int gemm_one(const vacnic_gemm_args* a, int tile_hint, void* stream) {
   if (force == 259) return launch_gemm<256, 256, 2, 4, 32, 4, true, true>(p, a->x_kstrided, a->w_kstrided, zsplits, s);   // ping-pong, W pieces issued mid-COMP (A/B)
   if (force == 260) return launch_gemm<256, 256, 2, 4, 64, 2, false>(p, a->x_kstrided, a->w_kstrided, zsplits, s);   // plain (non-pipelined) K loop, for A/B
   if (force == 261) return launch_gemm<128, 128, 2, 2, 64, 2, false>(p, a->x_kstrided, a->w_kstrided, zsplits, s);
+  if (force == 264) return launch_gemm<256, 128, 2, 4, 32, 4, true>(p, a->x_kstrided, a->w_kstrided, zsplits, s);   // ping-pong, half-width tile: problems with <= 128 tiles of 256x256
   if (force == 263) return launch_gemm<256, 256, 2, 4, 64, 2, true, true>(p, a->x_kstrided, a->w_kstrided, zsplits, s);   // 64-wide pipelined loop, staggered DMA issue (A/B)
   if (force == 262) return launch_gemm<256, 256, 2, 4, 64, 2, true, false>(p, a->x_kstrided, a->w_kstrided, zsplits, s);   // pipelined, no stagger
   if (big) return launch_gemm<256, 256, 2, 4, 32, 4, true>(p, a->x_kstrided, a->w_kstrided, zsplits, s);   // ping-pong loop
