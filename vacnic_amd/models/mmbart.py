@@ -86,14 +86,20 @@ class BartAttention(nn.Module):
         self.s_q = _spec(self.q_proj, t)
         self.s_out = _spec(self.out_proj, t)
 
-    def forward(self, hidden_states, key_value_states=None, key_mask=None, causal=False):
+    def project_kv(self, key_value_states):
+        """fused k|v projection of a cross-attention source (MFULL:478-484)."""
+        return ops.linear(key_value_states, self.k_proj.weight, self.s_kv)
+
+    def forward(self, hidden_states, key_value_states=None, key_mask=None, causal=False, kv=None):
+        """kv: optional precomputed project_kv(key_value_states)."""
         H = self.num_heads
-        if key_value_states is None:
+        if key_value_states is None and kv is None:
             kvq = ops.linear(hidden_states, self.k_proj.weight, self.s_kvq)
             ctx = ops.self_attention(kvq, key_mask, causal, H)
         else:
             q = ops.linear(hidden_states, self.q_proj.weight, self.s_q)
-            kv = ops.linear(key_value_states, self.k_proj.weight, self.s_kv)
+            if kv is None:
+                kv = self.project_kv(key_value_states)
             ctx = ops.cross_attention(q, kv, key_mask, H)
         return ops.linear(ctx, self.out_proj.weight, self.s_out)
 
@@ -185,12 +191,13 @@ class BartEncoderLayer(nn.Module):
                     hidden_states_img, hidden_states_face, hidden_states_ner = img_out, face_out, ner_out
                 else:
                     kv, hidden_states_img = ops.fork(hidden_states_img)
+                kv = self.cross_attn_img_ner.project_kv(kv)        # k|v projection of the [img ; prefix] tokens: also off the text chain
             a, r = ops.fork(h)
             h = self._ln(self.self_attn(a, key_mask=key_mask), r, self.self_attn_layer_norm)      # :697-707
             if br is not None:
                 cur.wait_stream(br)
             a, r = ops.fork(h)
-            h = self._ln(self.cross_attn_img_ner(a, key_value_states=kv, key_mask=None), r, self.img_ner_attn_layer_norm)   # :711-723
+            h = self._ln(self.cross_attn_img_ner(a, kv=kv, key_mask=None), r, self.img_ner_attn_layer_norm)   # :711-723
         else:
             a, r = ops.fork(h)
             h = self._ln(self.self_attn(a, key_mask=key_mask), r, self.self_attn_layer_norm)      # :726-736
