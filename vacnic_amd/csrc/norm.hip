@@ -478,16 +478,10 @@ extern "C" int vacnic_add_ln_bwd(const vacnic_add_ln_bwd_args* a, void* stream) 
                      (const bf16_t*)a->x, (const bf16_t*)a->residual, a->gamma, a->mean, a->rstd, (bf16_t*)a->dresidual, \
                      (bf16_t*)a->dx, a->dgamma, a->dbeta, a->R, (int)a->D, a->p_drop, a->seed, a->seed_dev)
   const int nch = nch_for(a->D);
-  if (a->R >= 8192) {
-    int64_t nb = (a->R + 15) / 16;
-    if (nb > 256) nb = 256;
-    switch (nch) {
-      case 1: LAUNCH_LN_BWD(1, 16, nb); break;
-      case 2: LAUNCH_LN_BWD(2, 16, nb); break;
-      case 3: LAUNCH_LN_BWD(3, 16, nb); break;
-      default: LAUNCH_LN_BWD(4, 16, nb); break;
-    }
-  } else {
+  // 4-wave blocks (<= 1024 of them).  16-wave blocks cut the same-address dgamma/dbeta atomics 4x and are 5 us faster when the
+  // kernel runs alone, but a 1024-thread block needs a completely free CU: beside the weight-gradient stream's GEMMs the
+  // launch then waits for whole CUs and takes 125 us instead of 48 (measured in the step: 431 vs 428 samples/s).
+  {
     int64_t nb = (a->R + 3) / 4;
     if (nb > 1024) nb = 1024;
     switch (nch) {
