@@ -281,6 +281,13 @@ int vacnic_beam_topk(const void* logits, const float* beam_scores, const int32_t
 /* dst[r] = src[idx[r]] for rows of row_bytes (multiple of 16): KV-cache beam reorder (_reorder_cache, MFULL:2066-2074). */
 int vacnic_gather_rows(const void* src, void* dst, const int64_t* idx, int64_t rows, int64_t row_bytes, void* stream);
 
+/* ---- input pipeline ---- */
+/* uint8 image [B][3][H][W] -> fp32 [B][3][H][W]: torchvision ToTensor (x / 255) then Normalize ((t - mean[c]) / std[c]) of
+ * TRAIN:741-764, with an optional per-image horizontal flip (flip[b] != 0; RandomHorizontalFlip, TRAIN:762 — the caller draws
+ * the coin).  IEEE divisions, so the result is bit-identical to the torch formula. */
+int vacnic_image_u8_normalize(const uint8_t* src, const uint8_t* flip, float* dst, int64_t B, int64_t H, int64_t W,
+                              float mean0, float mean1, float mean2, float std0, float std1, float std2, void* stream);
+
 /* ---- hardware probes (tests only): verify MFMA / ds_read_tr lane maps assumed by the kernels -- */
 int vacnic_probe_layouts(float* out, const float* src128, int64_t n_out, void* stream);
 

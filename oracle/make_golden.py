@@ -285,12 +285,68 @@ def run_clip_crosscheck():
     print("clip ok", o.pooler_output.abs().mean().item())
 
 
+COLLATE_CASES = {          # name -> (seed, batch size, forced per-sample edits)
+    "mixed": (11, 6, None),
+    "no_faces_anywhere": (12, 3, "nofaces"),
+    "single_name_row": (13, 4, "noname"),
+}
+DSG_FILE = "src/data/goodnews_dataset_entity_type_newsmep_ent_ent_pos.py"
+
+
+def collate_case_samples(case):
+    seed, n, edit = COLLATE_CASES[case]
+    samples = synthetic.make_samples(n, seed=seed)
+    for i, sm in enumerate(samples):
+        if edit == "nofaces":
+            sm["face_emb"] = sm["face_emb"][:0]
+        if edit == "noname":                               # every sample carries only the <NONAME> row: max_num_seq == 1 branch
+            sm["names_ids"] = np.array([[0, 50266, 2]], dtype=np.int64)
+    return samples
+
+
+def run_collate():
+    """The reference's collate_fn_goodnews_entity_type + its padding helpers (DSG:22-305, pure torch/python; the module itself
+    imports spacy/unidecode at the top, so the slice is exec'd like BatchSoftmax) over seeded synthetic per-sample records."""
+    src = open(os.path.join(REF, DSG_FILE)).read()
+    a = src.index("def collate_fn_goodnews_entity_type(batch):")
+    b = src.index("def make_new_entity_ids(")
+    ns = {"torch": torch}
+    exec(compile(src[a:b], "dsg_slice", "exec"), ns)
+    rec = {}
+    for case in COLLATE_CASES:
+        samples = collate_case_samples(case)
+        batch = []
+        for sm in samples:
+            f = sm["face_emb"].astype(np.float32)
+            batch.append({
+                "article": "", "article_ids": torch.from_numpy(sm["article_ids"])[None], "article_ner_mask_ids": torch.zeros((1, 1), dtype=torch.long),
+                "caption": "", "caption_ids": torch.from_numpy(sm["caption_ids"])[None], "caption_ids_clip": None,
+                "names_art": [], "org_norp_gpe_loc_art": [], "names_art_ids": torch.from_numpy(sm["names_art_ids"])[None],
+                "org_norp_gpe_loc_art_ids": torch.from_numpy(sm["names_art_ids"])[None], "names": [], "org_norp_gpe_loc": [],
+                "names_ids": sm["names_ids"].tolist(), "org_norp_gpe_loc_ids": sm["names_ids"].tolist(),
+                "all_gt_ner_ids": torch.zeros((1, 4), dtype=torch.long), "all_gt_ner": [],
+                "face_emb": f if len(f) else np.zeros((1, 0), dtype=np.float32),       # the dataset yields an empty 2-D array when no face was detected
+                "obj_emb": np.zeros((1, 0), dtype=np.float32), "img_tensor": torch.from_numpy(sm["image"].astype(np.float32))[None],
+                "person_id_positions": [], "person_id_positions_cap": [],
+                "names_ids_flatten": torch.from_numpy(sm["names_ids_flatten"])[None],
+                "org_norp_gpe_loc_ids_flatten": torch.from_numpy(sm["names_ids_flatten"])[None]})
+        out = ns["collate_fn_goodnews_entity_type"](batch)
+        for k in ("article_ids", "caption_ids", "names_art_ids", "names_ids", "names_ids_flatten", "face_emb", "img_tensor"):
+            rec[f"{case}:{k}"] = out[k].numpy()
+        print("collate", case, {k: tuple(out[k].shape) for k in ("article_ids", "caption_ids", "names_ids", "face_emb")})
+    np.savez_compressed(os.path.join(OUT, "collate.npz"), **rec)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     mfull, mvis, train, BatchSoftmax = import_reference()
     if len(sys.argv) > 1 and sys.argv[1] == "generate":
         run_generate_case(mfull, train)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "collate":
+        run_collate()
+        return
+    run_collate()
     run_helpers(train, BatchSoftmax)
     run_generate_case(mfull, train)
     run_clip_crosscheck()

@@ -446,3 +446,36 @@ def beam_search_decode(sd, cfg, input_ids, attention_mask, image_features, num_b
     with torch.no_grad():
         return beam_search_bookkeeping(step, B, num_beams, max_length, cfg.eos_token_id, cfg.pad_token_id,
                                        cfg.decoder_start_token_id, length_penalty, **gen)
+
+
+# ------------------------------------------------------------------------------------------------ input pipeline
+def collate_restated(samples, pad=1, bos=0, eos=2, noname=50266):
+    """Pure-python restatement of collate_fn_goodnews_entity_type for the fields the step reads (DSG:22-127) and its helpers
+    pad_sequence (DSG:201-216), pad_sequence_from_list (DSG:169-190) and pad_tensor_feat (DSG:272-305), sample by sample like the
+    reference.  Pinned by tests/golden/collate.npz (the reference's own functions run on the same records)."""
+    def pad_sequence(seqs):                                    # DSG:201-216 with max_len = longest in the batch
+        m = max(len(s) for s in seqs)
+        return torch.tensor([list(s) + [pad] * (m - len(s)) for s in seqs], dtype=torch.long)
+    out = {k: pad_sequence([s[k].tolist() for s in samples]) for k in ("article_ids", "caption_ids", "names_art_ids", "names_ids_flatten")}
+    lists = [s["names_ids"].tolist() for s in samples]
+    max_len = max(len(seq) for sl in lists for seq in sl)      # get_max_len_list, DSG:131-137
+    max_num = max(len(sl) for sl in lists)
+    rows_all = []
+    for sl in lists:                                           # DSG:169-190
+        rows = [seq + [pad] * (max_len - len(seq)) for seq in sl]
+        rows += [[bos, noname, eos] + [pad] * (max_len - 3)] * (max_num - len(sl))
+        rows_all.append(rows)
+    out["names_ids"] = torch.tensor(rows_all, dtype=torch.long)
+    lens = [s["face_emb"].shape[0] for s in samples]           # DSG:272-305
+    m = max(lens)
+    faces = []
+    for s, n in zip(samples, lens):
+        f = torch.from_numpy(s["face_emb"].astype("float32"))
+        if m == 0:
+            faces.append(torch.ones((1, 512)))
+        elif n < m:
+            faces.append(torch.cat((f, torch.ones((m - n, 512))), dim=0))
+        else:
+            faces.append(f)
+    out["face_emb"] = torch.stack(faces).float()
+    return out

@@ -419,3 +419,13 @@ def test_trainer_entry_point_runs_and_resumes(tmp_path):
     assert r2.returncode == 0, r2.stderr[-2000:]
     recs2 = [json.loads(l) for l in r2.stdout.splitlines() if l.startswith("{")]
     assert [r["step"] for r in recs2] == [4, 5, 6], recs2
+    # packed shard input: 6 samples, batch 2 -> 3 steps per epoch through the PrefetchLoader
+    from vacnic_amd import data, synthetic
+    with data.ShardWriter(os.path.join(str(tmp_path), "train.vshard")) as w:
+        for s_ in synthetic.make_samples(6, seed=2, max_article=64, image_size=224):
+            w.add(s_)
+    r3 = subprocess.run(common + ["--num_epoch", "1", "--data_type", "shard", "--data_dir", str(tmp_path), "--experiment_name", "u"],
+                        capture_output=True, text=True, timeout=600, env=env)
+    assert r3.returncode == 0, r3.stderr[-2000:]
+    recs3 = [json.loads(l) for l in r3.stdout.splitlines() if l.startswith("{")]
+    assert [r["step"] for r in recs3] == [1, 2, 3] and all(np.isfinite(r["loss"]) for r in recs3)

@@ -124,13 +124,27 @@ def run(args, batches=None):
         start_step = int(checkpoint.load_checkpoint(args.resume, net, opt)["step"])
         step = start_step
     for epoch in range(start_step // args.steps_per_epoch, int(args.num_epoch)):
-        it = batches if batches is not None else (
-            synthetic.make_batch(cfg, args.train_batch_size, S=args.article_max_length, T=min(64, args.caption_max_length), seed=int(args.seed) % 65536,
-                                 rank=rank, step=epoch * args.steps_per_epoch + i) for i in range(args.steps_per_epoch))
+        if batches is not None:
+            it = batches
+        elif args.data_type == "shard":
+            # packed pre-tokenised shard (vacnic_amd/data.py): sampler + collate + pinned staging + async H2D in the loader
+            from vacnic_amd import data
+            it = data.PrefetchLoader(data.ShardReader(os.path.join(args.data_dir, "train.vshard")), args.train_batch_size, rank=rank,
+                                     world=world, seed=int(args.seed) % 65536)
+            it.set_epoch(epoch)
+        else:
+            it = (synthetic.make_batch(cfg, args.train_batch_size, S=args.article_max_length, T=min(64, args.caption_max_length),
+                                       seed=int(args.seed) % 65536, rank=rank, step=epoch * args.steps_per_epoch + i)
+                  for i in range(args.steps_per_epoch))
         for bi, batch in enumerate(it):
             if epoch * args.steps_per_epoch + bi < start_step:
                 continue                                            # already consumed before the checkpoint
-            out4 = train_step(net, guide if not args.only_image else None, opt, to_device(batch, "cuda"), targs)
+            ready = None
+            if isinstance(batch, tuple):                            # (device batch, copy-stream event) from the PrefetchLoader
+                batch, ready = batch
+            else:
+                batch = to_device(batch, "cuda")
+            out4 = train_step(net, guide if not args.only_image else None, opt, batch, targs, ready)
             step += 1
             if step % args.log_every == 0 and rank == 0:          # ONE device->host sync per log interval (the reference does 4 per step)
                 tot, txt, secla, colam = out4.tolist()

@@ -135,6 +135,7 @@ _PLAIN_FNS = {
     "vacnic_probe_layouts": [vp, vp, i64, vp],
     "vacnic_beam_topk": [vp, vp, vp, i32, i32, i32, i32, vp, vp, i64, i64, i64, i32, i32, vp],
     "vacnic_gather_rows": [vp, vp, vp, i64, i64, vp],
+    "vacnic_image_u8_normalize": [vp, vp, vp, i64, i64, i64, f32, f32, f32, f32, f32, f32, vp],
 }
 EXPORTED = sorted(list(_STRUCT_FNS) + list(_PLAIN_FNS) + ["vacnic_last_error_string", "vacnic_version"])
 

@@ -265,3 +265,42 @@ extern "C" int vacnic_bias_grad(const void* dy, float* dbias, int64_t M, int64_t
   VLAUNCH_CHECK();
   return VACNIC_OK;
 }
+
+
+// ---- uint8 image -> normalised fp32 (ToTensor + Normalize + optional horizontal flip), 4 pixels per thread
+namespace {
+__global__ __launch_bounds__(256) void image_u8_normalize_kernel(const uint8_t* __restrict__ src, const uint8_t* __restrict__ flip,
+                                                                 float* __restrict__ dst, long B, int H, int W, float m0, float m1,
+                                                                 float m2, float s0, float s1, float s2) {
+  const long plane = (long)H * W, total = B * 3 * plane;
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (long)gridDim.x * 256 * 4) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const long j = i + e;
+      if (j >= total) break;
+      const long b = j / (3 * plane), r = j - b * 3 * plane;
+      const int c = (int)(r / plane);
+      const long yx = r - (long)c * plane;
+      const int y = (int)(yx / W), x = (int)(yx - (long)y * W);
+      const int sx = (flip && flip[b]) ? W - 1 - x : x;
+      const float t = (float)src[(b * 3 + c) * plane + (long)y * W + sx] / 255.0f;
+      const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+      dst[j] = (t - mean) / sd;
+    }
+  }
+}
+}  // namespace
+
+extern "C" int vacnic_image_u8_normalize(const uint8_t* src, const uint8_t* flip, float* dst, int64_t B, int64_t H, int64_t W,
+                                         float mean0, float mean1, float mean2, float std0, float std1, float std2, void* stream) {
+  VCHECK(src && dst, VACNIC_BAD_SHAPE, "image_u8_normalize: null operand");
+  VCHECK(B >= 0 && H > 0 && W > 0 && std0 != 0.f && std1 != 0.f && std2 != 0.f, VACNIC_BAD_SHAPE, "image_u8_normalize: bad shape / zero std");
+  const long total = B * 3 * H * W;
+  if (total == 0) return VACNIC_OK;
+  long nb = (total / 4 + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(image_u8_normalize_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, src, flip, dst, (long)B, (int)H,
+                     (int)W, mean0, mean1, mean2, std0, std1, std2);
+  VLAUNCH_CHECK();
+  return VACNIC_OK;
+}

@@ -388,5 +388,14 @@ def beam_topk(logits, V, K_, beam_scores=None, bans=None, eos=2, suppress_eos=Fa
     return tv, ti
 
 
+def image_u8_normalize(img_u8, flip=None, mean=(0.48145466, 0.4578275, 0.40821073), std=(0.26862954, 0.26130258, 0.27577711)):
+    """uint8 [B,3,H,W] (+ optional uint8 flip flags [B]) -> fp32 ToTensor + Normalize (TRAIN:741-764), bit-identical to torch."""
+    B, C, H, W = img_u8.shape
+    assert C == 3 and img_u8.dtype == torch.uint8 and img_u8.is_contiguous()
+    out = torch.empty((B, 3, H, W), device=img_u8.device, dtype=torch.float32)
+    call("vacnic_image_u8_normalize", _p(img_u8), _p(flip), _p(out), B, H, W, *[float(v) for v in mean], *[float(v) for v in std], _stream())
+    return out
+
+
 def gather_rows(src, dst, idx, rows, row_bytes):
     call("vacnic_gather_rows", _p(src), _p(dst), _p(idx), rows, row_bytes, _stream())

@@ -164,3 +164,36 @@ def make_batch(cfg: VacnicConfig, B, S=512, T=64, F=4, Nn=5, Ln=8, seed=42, rank
     t = torch.from_numpy
     return {"article_ids": t(article), "caption_ids": t(caption), "img_tensor": t(img), "face_emb": t(face),
             "names_art_ids": t(names_art), "names_ids": t(names_ids)}
+
+
+def make_samples(n, seed=0, max_article=96, max_caption=24, max_faces=4, max_names=4, image_size=32, ner_len=80, gt_len=20,
+                 pad=1, bos=0, eos=2, ent=50265, noname=50266, vocab=50265):
+    """Pre-tokenised per-sample records in the layout of vacnic_amd.data (what the reference's Dataset.__getitem__ produces,
+    DSG:524-659, minus the strings): variable-length article / caption ids, fixed-length names_art_ids / names_ids_flatten
+    (make_new_entity_ids pads them, DSG:352-354), names_ids rows padded per sample with the <NONAME> row last (DSG:356-358),
+    0..max_faces face embeddings, one uint8 image.  Deterministic in (seed, index)."""
+    out = []
+    for i in range(n):
+        g = np.random.default_rng([seed, i])
+        la, lc = int(g.integers(8, max_article + 1)), int(g.integers(4, max_caption + 1))
+        art = np.concatenate([[bos], g.integers(3, vocab, la - 2), [eos]]).astype(np.int64)
+        cap = np.concatenate([[bos], g.integers(3, vocab, lc - 2), [eos]]).astype(np.int64)
+        nn_ = int(g.integers(0, max_names + 1))
+        rows = [[bos] + g.integers(3, vocab, int(g.integers(1, 5))).tolist() + [eos] for _ in range(nn_)] + [[bos, noname, eos]]
+        w = max(len(r) for r in rows)
+        names_ids = np.array([r + [pad] * (w - len(r)) for r in rows], dtype=np.int64)
+        flat = [bos]
+        for r in rows[:-1]:
+            flat += r[1:-1] + [ent]
+        if nn_ == 0:
+            flat += [noname]
+        flat = (flat[:gt_len - 1] + [eos])
+        flat = np.array(flat + [pad] * (gt_len - len(flat)), dtype=np.int64)
+        na = [bos] + g.integers(3, vocab, int(g.integers(0, ner_len - 2))).tolist() + [eos]
+        names_art = np.array(na + [pad] * (ner_len - len(na)), dtype=np.int64)
+        nf = int(g.integers(0, max_faces + 1))
+        faces = (g.standard_normal((nf, 512)) / np.sqrt(512.0)).astype(np.float16)
+        img = g.integers(0, 256, (3, image_size, image_size), dtype=np.uint8)
+        out.append({"article_ids": art, "caption_ids": cap, "names_art_ids": names_art, "names_ids": names_ids,
+                    "names_ids_flatten": flat, "face_emb": faces, "image": img})
+    return out
