@@ -508,9 +508,14 @@ int check_common(int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t ldq, int6
 // One wave per (batch row, head): lanes split the keys for q.k, a wave reduction gives the softmax statistics, the
 // probabilities go through LDS, then lanes = (8 key groups) x (8 chunks of 8 dims) accumulate P.V and meet in three
 // shuffle steps.  fp32 throughout; same additive finfo.min mask semantics as the tiled kernel.
-__global__ __launch_bounds__(64) void attn_decode_kernel(AttnP p) {
-  extern __shared__ float probs[];                    // Tk floats
-  const int lane = threadIdx.x, h = blockIdx.x, b = blockIdx.y;
+template <int NWV>
+__global__ __launch_bounds__(64 * NWV) void attn_decode_kernel(AttnP p) {
+  extern __shared__ float probs[];                    // Tk floats, then the per-wave partial results
+  const int lane = threadIdx.x & 63, h = blockIdx.x, b = blockIdx.y;
+  const int wv = NWV == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // NWV waves split the keys into contiguous ranges (long cross-attention sources) and merge their softmax partials in LDS
+  const int per = (p.Tk + NWV - 1) / NWV;
+  const int k_lo = wv * per, k_hi = min(p.Tk, k_lo + per);
   const bf16_t* q = p.q + (long)b * p.bsq + h * 64;
   const bf16_t* kb = p.k + (long)b * p.bsk + h * 64;
   const bf16_t* vb = p.v + (long)b * p.bsv + h * 64;
@@ -525,19 +530,19 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(AttnP p) {
   float m = -INFINITY;
   // keys in batches of 4 per lane: all 32 16-byte loads of a batch are issued before the first is consumed (with one wave
   // per CU nothing else hides the ~2 us round trip of a load)
-  for (int key0 = lane; key0 < p.Tk; key0 += 256) {
+  for (int key0 = k_lo + lane; key0 < k_hi; key0 += 256) {
     u32x4 kr[4][8];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int key = key0 + 64 * u;
-      const bf16_t* krow = kb + (long)(key < p.Tk ? key : key0) * p.ldk;
+      const bf16_t* krow = kb + (long)(key < k_hi ? key : key0) * p.ldk;
 #pragma unroll
       for (int c = 0; c < 8; ++c) kr[u][c] = *(const u32x4*)(krow + c * 8);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int key = key0 + 64 * u;
-      if (key < p.Tk) {
+      if (key < k_hi) {
         float dot = 0.f;
 #pragma unroll
         for (int c = 0; c < 8; ++c)
@@ -555,7 +560,7 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(AttnP p) {
   }
   m = wave_max(m);
   float l = 0.f;
-  for (int key = lane; key < p.Tk; key += 64) {
+  for (int key = k_lo + lane; key < k_hi; key += 64) {
     const float e = __expf(probs[key] - m);
     probs[key] = e;
     l += e;
@@ -566,12 +571,12 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(AttnP p) {
   float acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-  for (int key0 = kg; key0 < p.Tk; key0 += 64) {
+  for (int key0 = k_lo + kg; key0 < k_hi; key0 += 64) {
     u32x4 vr[8]; float pk[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int key = key0 + 8 * u;
-      const bool ok = key < p.Tk;
+      const bool ok = key < k_hi;
       vr[u] = *(const u32x4*)(vb + (long)(ok ? key : key0) * p.ldv + dc * 8);
       pk[u] = ok ? probs[key] : 0.f;
     }
@@ -587,6 +592,34 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(AttnP p) {
   for (int o = 8; o < 64; o <<= 1)
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], o, 64);
+  if constexpr (NWV > 1) {
+    float* pacc = probs + p.Tk;                        // [NWV][64]
+    float* pm = pacc + NWV * 64;                       // [NWV]
+    float* pl = pm + NWV;                              // [NWV]
+    if (kg == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pacc[wv * 64 + dc * 8 + j] = acc[j];
+    }
+    if (lane == 0) { pm[wv] = m; pl[wv] = l; }
+    __syncthreads();
+    if (wv != 0) return;
+    float gm = pm[0];
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) gm = fmaxf(gm, pm[w]);
+    float gl = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) {
+      const float sc = pl[w] > 0.f ? __expf(pm[w] - gm) : 0.f;      // an empty key range contributes nothing
+      gl += pl[w] * sc;
+      if (kg == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += pacc[w * 64 + dc * 8 + j] * sc;
+      }
+    }
+    m = gm; l = gl;
+  }
   if (kg == 0) {
     const float inv = 1.f / l;
     bf16_t* o = p.out + (long)b * p.bso + h * 64 + dc * 8;
@@ -609,7 +642,8 @@ extern "C" int vacnic_attn_fwd(const vacnic_attn_fwd_args* a, void* stream) {
   p.bsq = a->bsq; p.bsk = a->bsk; p.bsv = a->bsv; p.bso = a->bso;
   p.causal = a->causal; p.scale = a->scale;
   if (p.Tq == 1 && !p.causal && p.Tk <= 16384) {      // decoder step: one wave per (row, head)
-    hipLaunchKernelGGL(attn_decode_kernel, dim3(p.H, p.B), dim3(64), (size_t)p.Tk * 4, (hipStream_t)stream, p);
+    if (p.Tk >= 256) hipLaunchKernelGGL(attn_decode_kernel<4>, dim3(p.H, p.B), dim3(256), (size_t)(p.Tk + 4 * 64 + 8) * 4, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(attn_decode_kernel<1>, dim3(p.H, p.B), dim3(64), (size_t)p.Tk * 4, (hipStream_t)stream, p);
     VLAUNCH_CHECK();
     return VACNIC_OK;
   }

@@ -606,11 +606,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
 // GEMM whose X is a handful of rows.  HBM-bound: W [N,K] is streamed exactly once; X (<= 8 x K bf16) is re-read from
 // L1/L2.  One wave owns CW consecutive output columns; its 64 lanes split K in 16-byte chunks, accumulate MR x CW partial
 // dot products in fp32 and meet in a wave reduction.  No LDS, no barriers.
-template <int MR, int CW>
-__global__ __launch_bounds__(64) void gemm_skinny_kernel(GemmP p) {
-  // one wave per workgroup: N / CW independent waves spread over every CU (N = 1024 -> 256 workgroups), each limited only
-  // by one round trip of its loads
-  const int lane = threadIdx.x;
+template <int MR, int CW, int KW>
+__global__ __launch_bounds__(64 * KW) void gemm_skinny_kernel(GemmP p) {
+  // one workgroup per CW output columns: N / CW independent workgroups spread over every CU (N = 1024 -> 256), each limited
+  // only by one round trip of its loads.  KW waves split K (long reductions, e.g. fc2 with K = 4096) and meet through LDS.
+  const int lane = threadIdx.x & 63;
+  const int kw = KW == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n0 = blockIdx.x * CW;
   constexpr int NV = MR * CW;                        // 32 partial dot products per lane
   float acc[NV];
@@ -618,7 +619,7 @@ __global__ __launch_bounds__(64) void gemm_skinny_kernel(GemmP p) {
   for (int i = 0; i < NV; ++i) acc[i] = 0.f;
   const int nchunk = p.K >> 3;                       // host guarantees K % 8 == 0
 #pragma unroll 4
-  for (int ch = lane; ch < nchunk; ch += 64) {
+  for (int ch = lane + 64 * kw; ch < nchunk; ch += 64 * KW) {
     float wv[CW][8];
 #pragma unroll
     for (int c = 0; c < CW; ++c) {
@@ -655,8 +656,17 @@ __global__ __launch_bounds__(64) void gemm_skinny_kernel(GemmP p) {
   VAC_BFLY(32, 16) VAC_BFLY(16, 8) VAC_BFLY(8, 4) VAC_BFLY(4, 2) VAC_BFLY(2, 1)
 #undef VAC_BFLY
   float v = acc[0] + __shfl_xor(acc[0], 1, 64);
+  const int idx = (((lane >> 5) & 1) << 4) | (((lane >> 4) & 1) << 3) | (((lane >> 3) & 1) << 2) | (((lane >> 2) & 1) << 1) | ((lane >> 1) & 1);
+  if constexpr (KW > 1) {
+    __shared__ float part[KW][NV];
+    if ((lane & 1) == 0) part[kw][idx] = v;
+    __syncthreads();
+    if (kw != 0) return;
+    v = 0.f;
+#pragma unroll
+    for (int w = 0; w < KW; ++w) v += part[w][idx];
+  }
   if ((lane & 1) == 0) {
-    const int idx = (((lane >> 5) & 1) << 4) | (((lane >> 4) & 1) << 3) | (((lane >> 3) & 1) << 2) | (((lane >> 2) & 1) << 1) | ((lane >> 1) & 1);
     const int m = idx / CW, c = idx % CW;
     const int n = n0 + c;
     if (m < p.M && n < p.N) {
@@ -801,7 +811,8 @@ static int gemm_one(const vacnic_gemm_args* a, int tile_hint, void* stream) {
            (a->K & 7) == 0, VACNIC_UNSUPPORTED, "gemm: the skinny kernel needs M <= 8, K-contiguous operands, K %% 8 == 0 and a plain epilogue");
     constexpr int CW = 4;
     dim3 grid((unsigned)((a->N + CW - 1) / CW));
-    hipLaunchKernelGGL((gemm_skinny_kernel<8, CW>), grid, dim3(64), 0, s, p);
+    if (a->K >= 2048 && a->N <= 8192) hipLaunchKernelGGL((gemm_skinny_kernel<8, CW, 4>), grid, dim3(256), 0, s, p);   // long reduction, few columns: 4 waves split K
+    else hipLaunchKernelGGL((gemm_skinny_kernel<8, CW, 1>), grid, dim3(64), 0, s, p);
     VLAUNCH_CHECK();
     return VACNIC_OK;
   }
