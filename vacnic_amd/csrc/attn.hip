@@ -105,6 +105,7 @@ __device__ __forceinline__ void fill_key_bias(float* kbias, const uint8_t* mask_
 // =================================================================================================
 // forward:  S^T = K Q^T (keys in registers, query on the lane) -> online softmax -> O^T = V^T P^T
 // =================================================================================================
+template <bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -123,11 +124,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   __amdgpu_buffer_rsrc_t vs = make_rsrc(vb, p.Tk, p.ldv);
 
   int ntile = Tk_pad >> 6;
-  if (p.causal) ntile = min(ntile, (min(p.Tq, (int)blockIdx.x * 128 + 128) + 63) >> 6);
+  if (CAUSAL) ntile = min(ntile, (min(p.Tq, (int)blockIdx.x * 128 + 128) + 63) >> 6);
 
   stage64(ks, smem, 0, p.Tk, p.ldk, wave, lane);
   stage64(vs, smem + TILE_B, 0, p.Tk, p.ldv, wave, lane);
   fill_key_bias(kbias, p.key_mask ? p.key_mask + (long)b * p.Tk : nullptr, p.Tk, Tk_pad);
+  // scores live in the log2 domain (v_exp_f32 is 2^x): scale*log2(e) folded into one FMA per score, masks as -FLT_MAX (they
+  // absorb any finite score exactly like the reference's additive finfo.min, and two of them overflow to -inf like there)
+  const float scale2 = p.scale * 1.4426950408889634f;
 
   // Q fragments (B operand: element j = Q[q][16*ks + 8*hh + j]) straight from HBM
   bf16x8 qf[4];
@@ -176,8 +180,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
         const f32x4 bias = *(const f32x4*)(kbias + kbase);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float v = s[kb2][4 * g + e] * p.scale + bias[e];
-          if (p.causal && (kbase + e) > qidx) v += FMIN;
+          float v = fmaf(s[kb2][4 * g + e], scale2, bias[e]);
+          if (CAUSAL && (kbase + e) > qidx) v += FMIN;
           s[kb2][4 * g + e] = v;
           tmax = fmaxf(tmax, v);
         }
@@ -185,13 +189,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
     }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
     const float m_new = fmaxf(m_run, tmax);
-    const float alpha = __expf(m_run - m_new);   // m_run = -inf on the first tile -> 0
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // m_run = -inf on the first tile -> 0
     float psum = 0.f;
 #pragma unroll
     for (int kb2 = 0; kb2 < 2; ++kb2)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float e = __expf(s[kb2][r] - m_new);
+        const float e = __builtin_amdgcn_exp2f(s[kb2][r] - m_new);
         s[kb2][r] = e;
         psum += e;
       }
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
                     pack2bf(o[hb][4 * g + 2] * inv, o[hb][4 * g + 3] * inv)};
         *(u32x2*)(orow + hb * 32 + 8 * g + 4 * hh) = pk;
       }
-    if (p.lse && hh == 0) p.lse[((long)b * p.H + hd) * p.Tq + qidx] = m_run + __logf(l_tot);
+    if (p.lse && hh == 0) p.lse[((long)b * p.H + hd) * p.Tq + qidx] = m_run * 0.6931471805599453f + __logf(l_tot);
   }
 }
 
@@ -649,7 +653,8 @@ extern "C" int vacnic_attn_fwd(const vacnic_attn_fwd_args* a, void* stream) {
   }
   const int Tk_pad = (p.Tk + 63) & ~63;
   dim3 grid((p.Tq + 127) / 128, p.H, p.B);
-  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 4 * TILE_B + Tk_pad * 4, (hipStream_t)stream, p);
+  if (p.causal) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 4 * TILE_B + Tk_pad * 4, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 4 * TILE_B + Tk_pad * 4, (hipStream_t)stream, p);
   VLAUNCH_CHECK();
   return VACNIC_OK;
 }
