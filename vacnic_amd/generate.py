@@ -68,7 +68,10 @@ class CachedDecoder:
         self.d, self.H = d, model.config.decoder_attention_heads
         self.rows, self.Tmax, self.S, self.reorders = rows, max_length, S, reorders
         dev = model.emb16_pad.device
-        self.cache = [torch.zeros((self.L, rows, max_length, 2 * d), device=dev, dtype=BF16) for _ in range(2 if reorders else 1)]
+        # one extra position per row: the fused k|v|q projection of position t is written IN PLACE at [row, t, 0:3d] — k|v
+        # land in their cache slot, q parks in the first d columns of position t+1 (overwritten by that position's own k
+        # before anything reads it), so no append copy is needed (MFULL:489-492 does torch.cat per step)
+        self.cache = [torch.zeros((self.L, rows, max_length + 1, 2 * d), device=dev, dtype=BF16) for _ in range(2 if reorders else 1)]
         self.enc_b = torch.empty((rows, S, d), device=dev, dtype=BF16)
         self.enc_mask = torch.empty((rows, S), device=dev, dtype=torch.uint8)
         self.cross = [torch.empty((rows, S, 2 * d), device=dev, dtype=BF16) for _ in range(self.L)]
@@ -98,9 +101,10 @@ class CachedDecoder:
         cache = self.cache_at(t)
         for li, layer in enumerate(dec.layers):
             a = layer.self_attn
-            kvq = K.gemm(h.view(R, d), a.s_kvq.w16, R, 3 * d, d, bias=a.s_kvq.bias).view(R, 1, 3 * d)
-            K.copy3d(kvq[..., :2 * d], cache[li][:, t:t + 1], R, 1, 2 * d)                      # append k|v (MFULL:489-492)
-            ctx, _ = K.attn_fwd(kvq[..., 2 * d:], cache[li][:, :t + 1, :d], cache[li][:, :t + 1, d:], R, H, 1, t + 1, need_lse=False)
+            row = cache[li][:, t]                                                               # [R, 2d] view, row stride (Tmax+1)*2d
+            K.gemm(h.view(R, d), a.s_kvq.w16, R, 3 * d, d, bias=a.s_kvq.bias, out=row, ldo=row.stride(0))   # k|v|q in place
+            q = cache[li][:, t + 1:t + 2, :d]
+            ctx, _ = K.attn_fwd(q, cache[li][:, :t + 1, :d], cache[li][:, :t + 1, d:], R, H, 1, t + 1, need_lse=False)
             o = K.gemm(ctx.view(R, d), a.s_out.w16, R, d, d, bias=a.s_out.bias)
             h, _, _ = K.add_ln_fwd(o.view(R, 1, d), h, layer.self_attn_layer_norm.weight.data, layer.self_attn_layer_norm.bias.data,
                                    need_stats=False)
@@ -123,7 +127,7 @@ class CachedDecoder:
         MFULL:2066-2074): cache[(t-1)&1] gathered into cache[t&1]."""
         L, R = self.L, self.rows
         idx = (self.lidx + beam_idx[None, :]).reshape(-1)
-        K.gather_rows(self.cache[(t - 1) & 1], self.cache[t & 1], idx, L * R, self.Tmax * 2 * self.d * 2)
+        K.gather_rows(self.cache[(t - 1) & 1], self.cache[t & 1], idx, L * R, (self.Tmax + 1) * 2 * self.d * 2)
 
 
 class DecodeSession:
