@@ -429,3 +429,35 @@ def test_trainer_entry_point_runs_and_resumes(tmp_path):
     assert r3.returncode == 0, r3.stderr[-2000:]
     recs3 = [json.loads(l) for l in r3.stdout.splitlines() if l.startswith("{")]
     assert [r["step"] for r in recs3] == [1, 2, 3] and all(np.isfinite(r["loss"]) for r in recs3)
+
+
+def test_whole_step_hipgraph_replays_like_eager():
+    """opt-in `bench.py --graph` path: the full step (all side streams, LR / dropout counters in device memory) captured once;
+    replays must train like eager steps on the same batches (dropout off so the two runs are comparable)."""
+    from vacnic_amd import ops, streams, synthetic
+    from vacnic_amd.config import ClipVisionConfig
+    from vacnic_amd.training import FusedAdamW, GraphedTrainStep, TrainArgs, build_models, to_device, train_step
+    cfg = small_cfg(dropout=0.0, encoder_layers=1, decoder_layers=1)
+    vcfg = ClipVisionConfig(width=768, layers=1, patch_size=16, image_size=32, output_dim=64)
+    args = TrainArgs(num_training_steps=20, warmup_rate=0.1, lr_bart=1e-4)
+    batches = [to_device(synthetic.make_batch(cfg, 3, S=32, T=12, F=3, seed=40 + i, image_size=32), "cuda") for i in range(3)]
+    streams.enable(True)
+    try:
+        runs = []
+        for graphed in (False, True):
+            ops.Rng.manual_seed(3); ops.Rng.device_counter().zero_()
+            model, guide, _ = build_models(cfg, vcfg, init="synthetic", seed=0)
+            opt = FusedAdamW(model.arena, lr=args.lr_bart, weight_decay=args.weight_decay, num_warmup_steps=2, num_training_steps=20)
+            if graphed:
+                step = GraphedTrainStep(model, guide, opt, args, batches[0], warmup=2)      # 2 eager warm-up steps + the capture pass (not executed)
+                losses = [step(b).tolist() for b in batches]
+            else:
+                for _ in range(2):
+                    train_step(model, guide, opt, batches[0], args)
+                losses = [train_step(model, guide, opt, b, args).tolist() for b in batches]
+            torch.cuda.synchronize()
+            runs.append(np.array(losses))
+        assert np.isfinite(runs[1]).all()
+        np.testing.assert_allclose(runs[1], runs[0], rtol=5e-3, atol=1e-4)
+    finally:
+        streams.enable(False)
