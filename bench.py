@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--cap", type=int, default=64, help="caption tokens T")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=1)
+    ap.add_argument("--grad-transport", choices=("fp32", "bf16"), default="fp32",
+                    help="N>1: dtype of the gradient all-reduce (fp32 = the reference's DDP; bf16 halves the xGMI volume)")
     ap.add_argument("--no-streams", action="store_true", help="single-stream schedule (no side streams for guide / wgrad)")
     ap.add_argument("--no-tower-graphs", action="store_true", help="launch the frozen guide/ViT forwards eagerly instead of as two hipGraph replays")
     ap.add_argument("--graph", action="store_true", help="replay the step as one captured hipGraph (world 1 only). Measured slower than "
@@ -198,7 +200,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
-    net = DistributedDataParallel(model) if world > 1 else model
+    net = DistributedDataParallel(model, grad_transport=a.grad_transport) if world > 1 else model
     use_graph = world == 1 and a.graph
     log(f"batches resident; warm-up ({'hipGraph capture' if use_graph else 'eager'})")
     graphed = None

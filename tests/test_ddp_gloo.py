@@ -60,6 +60,17 @@ def _worker(rank, world, port, q):
         m.arena.grad.fill_(float(rank))
         w.reduce_gradients()
         assert torch.allclose(m.arena.grad, torch.ones_like(m.arena.grad))
+        # bf16 gradient transport: buckets rounded to bf16, summed, widened back (within bf16 resolution of the fp32 sum)
+        w16 = ddp.DistributedDataParallel(m, bucket_bytes=1 << 20, grad_transport="bf16")
+        gen = torch.Generator().manual_seed(7 + rank)
+        mine = torch.randn(m.arena.n, generator=gen)
+        both = mine.clone()
+        dist.all_reduce(both)
+        m.arena.grad.copy_(mine)
+        w16.reduce_gradients()
+        err = (m.arena.grad - both).abs().max().item()
+        assert err <= 2.0 ** -7 * both.abs().max().item() and err > 0.0, err
+        assert not w16.works and not w16.launched
         # expect() is ignored when the caller says no grad is needed (inference under no_grad)
         ddp.expect(False, params[0].grad)
         assert all(v == 0 for v in tr.pending.values())

@@ -78,7 +78,7 @@ class DistributedDataParallel(torch.nn.Module):
     (or use `vacnic_amd.training.train_step`, which does).  With world_size 1 it is a no-op shell."""
 
     def __init__(self, module, device_ids=None, output_device=None, process_group=None, bucket_bytes=256 << 20,
-                 overlap=True):
+                 overlap=True, grad_transport="fp32"):
         super().__init__()
         global TRACKER
         self.module = module
@@ -91,6 +91,15 @@ class DistributedDataParallel(torch.nn.Module):
         self.launched = set()
         self.comm_stream = None
         self.tracker = None
+        # grad_transport="bf16": every bucket is rounded to bf16, summed by the collective in bf16 and widened back — half the
+        # bytes on the xGMI links (PyTorch's bf16_compress_hook arithmetic).  The reference all-reduces fp32 (TRAIN:87), so fp32
+        # stays the default; bf16 is the documented throughput option.
+        if grad_transport not in ("fp32", "bf16"):
+            raise ValueError("grad_transport must be 'fp32' or 'bf16'")
+        self.transport = grad_transport
+        self.stage16 = None
+        if self.world > 1 and grad_transport == "bf16":
+            self.stage16 = torch.empty(self.arena.n, device=self.arena.grad.device, dtype=torch.bfloat16)
         if self.world > 1:
             # (i) ctor broadcast of all params from rank 0 (TRAIN:87); buffers on this path are constants
             dist.broadcast(self.arena.flat32, src=0, group=self.pg)
@@ -110,19 +119,31 @@ class DistributedDataParallel(torch.nn.Module):
         if start in self.launched:
             return
         self.launched.add(start)
-        g = self.arena.grad[start:self.bucket_end[start]]
+        end = self.bucket_end[start]
+        g = self.arena.grad[start:end]
+        s16 = self.stage16[start:end] if self.stage16 is not None else None
         if self.comm_stream is not None:
             # the bucket's writers may sit on the compute stream (LN / embedding grads) and on the weight-gradient
             # side stream (wgrad GEMMs): the collective waits for both
+            from . import kernels as K
             from . import streams
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             for s in (streams.wgrad_stream(), streams.branch_stream(), torch.cuda.default_stream()):
                 if s is not None:
                     self.comm_stream.wait_stream(s)
             with torch.cuda.stream(self.comm_stream):
-                self.works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
-        else:
+                if s16 is None:
+                    self.works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                else:
+                    K.cast_f32_bf16(g, s16)
+                    w = dist.all_reduce(s16, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                    w.wait()                                  # stream dependency only (NCCL work): comm stream follows the collective
+                    K.cast_bf16_f32(s16, g)
+        elif s16 is None:
             self.works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        else:                                                 # host arenas (gloo tests)
+            s16.copy_(g)
+            self.works.append((dist.all_reduce(s16, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), s16, g))
 
     def reduce_gradients(self):
         """Finish the step's gradient all-reduce: launch whatever backward did not already launch, then make the
@@ -132,7 +153,13 @@ class DistributedDataParallel(torch.nn.Module):
         for start, _ in self.tracker.buckets:
             self._launch_bucket(start)
         for w in self.works:
-            w.wait()
+            if isinstance(w, tuple):
+                w[0].wait()
+                w[2].copy_(w[1])
+            else:
+                w.wait()
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)     # bf16 transport finishes with a cast on the comm stream
         self.works.clear()
         self.launched.clear()
         self.tracker.reset()

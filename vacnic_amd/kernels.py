@@ -291,9 +291,10 @@ def cast_f32_bf16(src, dst=None):
     return dst
 
 
-def cast_bf16_f32(src):
-    dst = torch.empty(src.shape, device=src.device, dtype=torch.float32)
-    assert src.is_contiguous()
+def cast_bf16_f32(src, dst=None):
+    if dst is None:
+        dst = torch.empty(src.shape, device=src.device, dtype=torch.float32)
+    assert src.is_contiguous() and dst.is_contiguous()
     call("vacnic_cast_bf16_f32", _p(src), _p(dst), src.numel(), _stream())
     return dst
 
