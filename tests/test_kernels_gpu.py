@@ -131,7 +131,7 @@ def test_gemm_row_split_dispatch(K):
     close(o32, x.float() @ w.float().t(), 1e-3, 1e-3, "K-strided X, f32 out across the split")
 
 
-@pytest.mark.parametrize("hint", [64, 128, 256, 257, 260, 261, 262, 263, 264])
+@pytest.mark.parametrize("hint", [64, 128, 256, 260, 261, 262, 264])
 @pytest.mark.parametrize("M,N,K_", [(300, 520, 200), (1024, 768, 512), (257, 255 + 1, 64)])
 def test_gemm_all_layouts_both_tile_configs(K, hint, M, N, K_):
     x = rnd(M, K_, seed=1); w = rnd(N, K_, scale=0.1, seed=2); b = rnd(N, dtype=torch.float32, seed=3)

@@ -4,13 +4,16 @@
 // _linear_1up/down :587-588, _face_up/down :607-608, ner_map_up/down :594-595, prompt_mlp :1136,
 // visual_map :1144, lm_head :1885) and their dgrad / wgrad.
 //
-// Design (CDNA4): block tile BMxBNx64 with WMxWN waves, each wave a (BM/WM)x(BN/WN) sub-tile of
-// v_mfma_f32_16x16x32_bf16 tiles.  Two instantiations: 256x256 with 8 waves (2x4, 128x64 per wave,
-// 128 KiB LDS, one block per CU) for the large training GEMMs, 128x128 with 4 waves (2 blocks per CU)
-// when that fills the chip, and 64x128 with a 4-deep LDS ring for the small (latency-bound) problems.  Operands go HBM -> LDS with
-// `buffer_load_dwordx4 ... lds` (LDS-DMA, no VGPR round trip; the SRD range check zero-fills M/N/K
-// edges), double buffered, ONE barrier per K-tile: the loads of tile t+1 are issued before the MFMAs
-// of tile t and retired (vmcnt(0)) after them.  The LDS image is lane-linear per wave-instruction,
+// Design (CDNA4): block tile BMxBN with WMxWN waves, each wave a (BM/WM)x(BN/WN) sub-tile of v_mfma_f32_16x16x32_bf16
+// tiles.  Configurations (chosen per launch by the host cost model below, or forced by tile_hint):
+//   256x256, 8 waves (2x4, 128x64 per wave), 32-wide K stages in a 4-slot LDS ring (128 KiB, one block per CU), PING-PONG
+//            K loop: the two waves of every SIMD alternate MFMA and LDS/DMA phases — the large training GEMMs;
+//   128x128, 4 waves, 64-wide K tiles, two blocks per CU, software-pipelined loop (barrier in the middle of the tile's MFMAs),
+//            register->global epilogue — when that fills the chip better;
+//   64x128,  4 waves, 4-deep ring — small latency-bound problems;   256x128 ping-pong (hint 264);
+//   skinny   (M <= 8): W-streaming kernel without LDS — the single-token decoder.
+// Operands go HBM -> LDS with `buffer_load_dwordx4 ... lds` (LDS-DMA, no VGPR round trip; the SRD range check zero-fills
+// M/N/K edges) with counted vmcnt waits.  The LDS image is lane-linear per wave-instruction,
 // so the bank-conflict XOR swizzle is applied to the per-lane SOURCE address and again on the
 // fragment read (guide rule 21).  An operand whose reduction index is the strided one in memory
 // (dgrad's W, wgrad's dY and X) is staged as [k][row] and read with ds_read_b64_tr_b16 (hardware
@@ -235,7 +238,7 @@ __device__ __forceinline__ void epilogue8(const GemmP& p, float v[8], int m, int
 template <int N>
 __device__ __forceinline__ void wait_vm_lgkm() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
 
-template <int BM, int BN, int WM, int WN, int BKT, int NSTAGE, bool PIPE, bool STAGGER, bool XKS, bool WKS>
+template <int BM, int BN, int WM, int WN, int BKT, int NSTAGE, bool PIPE, bool XKS, bool WKS>
 __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
   constexpr int NWAVE = WM * WN, NTHR = 64 * NWAVE;
   constexpr int TM = BM / WM, TN = BN / WN;             // per-wave output sub-tile
@@ -304,10 +307,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
     // its slot with stage j+4.  A wave leaves MEM(h) only when its own pieces of stage h+1 have landed (vmcnt(8): stages
     // h+2, h+3 may fly), and a barrier separates that from every later reader.
     static_assert(NWAVE == 8 && LOADS >= 2, "ping-pong loop is written for 8 waves (two per SIMD)");
-    // DMA placement (STAGGER template flag reused as the switch): false = all four pieces in MEM(h); true = the X pieces in
-    // MEM(h), the W pieces in the middle of COMP(h) — MEM carries 12 ds_reads + its wait already, and a phase pair is as long
-    // as its longer half.
-    constexpr bool SPLIT_DMA = STAGGER;
+    // (Issuing part of the DMA pieces in the middle of COMP(h) instead, or staggering the partners' issue points in a 64-wide
+    // pipelined loop, measured the same within noise: profiles/r1_gemm_overhead.txt.)
     const bool grp_b = wave >= NWAVE / 2;
     const int nst = ntile;
     bf16x8 xf[FA], wf[FB];
@@ -324,26 +325,16 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
       }
       if (!(p.debug & 32)) {
         stage_tile<XKS, BM, BKT, NWAVE>(xs, xw, m0, RX, kbeg + (h + 3) * BKT, kend, p.ldx, wave, lane);
-        if (!SPLIT_DMA) stage_tile<WKS, BN, BKT, NWAVE>(ws, xw + XT, n0, RW, kbeg + (h + 3) * BKT, kend, p.ldw, wave, lane);
+        stage_tile<WKS, BN, BKT, NWAVE>(ws, xw + XT, n0, RW, kbeg + (h + 3) * BKT, kend, p.ldw, wave, lane);
       }
       // stage h+1 must have landed (this wave's pieces); newer ones may fly
-      wait_vm_lgkm<SPLIT_DMA ? 3 * LOADS / 2 : 2 * LOADS>();
+      wait_vm_lgkm<2 * LOADS>();
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int b = 0; b < FB / 2; ++b)
-#pragma unroll
-        for (int a = 0; a < FA; ++a)
-          acc[b][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b], xf[a], acc[b][a], 0, 0, 0);
-      if (SPLIT_DMA && !(p.debug & 32)) {
-        __builtin_amdgcn_sched_barrier(0);
-        stage_tile<WKS, BN, BKT, NWAVE>(ws, xw + XT, n0, RW, kbeg + (h + 3) * BKT, kend, p.ldw, wave, lane);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#pragma unroll
-      for (int b = FB / 2; b < FB; ++b)
+      for (int b = 0; b < FB; ++b)
 #pragma unroll
         for (int a = 0; a < FA; ++a)
           acc[b][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b], xf[a], acc[b][a], 0, 0, 0);
@@ -364,11 +355,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
     // - at the barrier every fragment of tile t is already in registers, so slot t is free: the loads of tile t+2 are
     //   issued right behind it and have a FULL iteration to land (a 64 KiB tile needs ~0.9 us at the per-CU L2->LDS rate
     //   plus latency; a load issued half an iteration before its wait stalls the whole workgroup);
-    // - SIMD partners (waves w and w+NWAVE/2) issue their LDS-DMA pieces at different points of the iteration (STAGGER:
-    //   right behind the barrier / in the middle of the kk=1 MFMAs), so one keeps the matrix pipe busy while the other
-    //   pays the ~45-cycle issue cost per piece.
     bf16x8 xf0[FA], wf0[FB], xf1[FA], wf1[FB];
-    const bool late = STAGGER && wave >= NWAVE / 2;
 #pragma unroll
     for (int a = 0; a < FA; ++a) xf0[a] = read_frag<XKS, BM, BKT>(smem, wm * TM + a * 16, 0, lane);
 #pragma unroll
@@ -388,10 +375,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
       // tile t+1 landed (all of this wave's loads), every LDS read of slot t retired
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      if (!late) {
-        stage_tile<XKS, BM, BKT, NWAVE>(xs, xcur, m0, RX, kbeg + (t + 2) * BKT, kend, p.ldx, wave, lane);
-        stage_tile<WKS, BN, BKT, NWAVE>(ws, wcur, n0, RW, kbeg + (t + 2) * BKT, kend, p.ldw, wave, lane);
-      }
+      stage_tile<XKS, BM, BKT, NWAVE>(xs, xcur, m0, RX, kbeg + (t + 2) * BKT, kend, p.ldx, wave, lane);
+      stage_tile<WKS, BN, BKT, NWAVE>(ws, wcur, n0, RW, kbeg + (t + 2) * BKT, kend, p.ldw, wave, lane);
       cur ^= 1;
       {
         const char* xn = smem + cur * STAGE;           // tile t+1 (zero-filled past the end: harmless)
@@ -401,16 +386,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
         for (int b = 0; b < FB; ++b) wf0[b] = read_frag<WKS, BN, BKT>(xn + XT, wn * TN + b * 16, 0, lane);
       }
 #pragma unroll
-      for (int b = 0; b < FB / 2; ++b)
-#pragma unroll
-        for (int a = 0; a < FA; ++a)
-          acc[b][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[b], xf1[a], acc[b][a], 0, 0, 0);
-      if (late) {
-        stage_tile<XKS, BM, BKT, NWAVE>(xs, xcur, m0, RX, kbeg + (t + 2) * BKT, kend, p.ldx, wave, lane);
-        stage_tile<WKS, BN, BKT, NWAVE>(ws, wcur, n0, RW, kbeg + (t + 2) * BKT, kend, p.ldw, wave, lane);
-      }
-#pragma unroll
-      for (int b = FB / 2; b < FB; ++b)
+      for (int b = 0; b < FB; ++b)
 #pragma unroll
         for (int a = 0; a < FA; ++a)
           acc[b][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[b], xf1[a], acc[b][a], 0, 0, 0);
@@ -681,7 +657,7 @@ __global__ __launch_bounds__(64 * KW) void gemm_skinny_kernel(GemmP p) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, int BKT, int NSTAGE, bool PIPE = false, bool STAGGER = false>
+template <int BM, int BN, int WM, int WN, int BKT, int NSTAGE, bool PIPE = false>
 int launch_gemm(const GemmP& p0, bool xks, bool wks, int zsplits, hipStream_t s) {
   GemmP p = p0;
   p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
@@ -690,7 +666,7 @@ int launch_gemm(const GemmP& p0, bool xks, bool wks, int zsplits, hipStream_t s)
   static_assert(lds >= 64 * (BN + 4) * 4, "epilogue staging must fit in the operand buffers");
 #define VAC_LAUNCH(XK, WK)                                                                            \
   do {                                                                                                \
-    auto kern = gemm_kernel<BM, BN, WM, WN, BKT, NSTAGE, PIPE, STAGGER, XK, WK>;                                                  \
+    auto kern = gemm_kernel<BM, BN, WM, WN, BKT, NSTAGE, PIPE, XK, WK>;                                                  \
     if (lds > 65536) {                                                                                \
       static bool once = false;                                                                       \
       if (!once) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; } \
@@ -820,14 +796,11 @@ static int gemm_one(const vacnic_gemm_args* a, int tile_hint, void* stream) {
   p.debug = tile_hint / 1000;
   const bool big = force == 256;
   const bool mid = force == 128;
-  if (force == 257) return launch_gemm<256, 128, 2, 2, 32, 3>(p, a->x_kstrided, a->w_kstrided, zsplits, s);   // experimental: 2 blocks/CU
-  if (force == 258) return launch_gemm<256, 256, 2, 4, 32, 4>(p, a->x_kstrided, a->w_kstrided, zsplits, s);   // experimental: deeper ring
-  if (force == 259) return launch_gemm<256, 256, 2, 4, 32, 4, true, true>(p, a->x_kstrided, a->w_kstrided, zsplits, s);   // ping-pong, W pieces issued mid-COMP (A/B)
-  if (force == 260) return launch_gemm<256, 256, 2, 4, 64, 2, false>(p, a->x_kstrided, a->w_kstrided, zsplits, s);   // plain (non-pipelined) K loop, for A/B
+  // A/B baselines kept for the ablations in profiles/: plain K loops and the 64-wide software-pipelined loop
+  if (force == 260) return launch_gemm<256, 256, 2, 4, 64, 2, false>(p, a->x_kstrided, a->w_kstrided, zsplits, s);
   if (force == 261) return launch_gemm<128, 128, 2, 2, 64, 2, false>(p, a->x_kstrided, a->w_kstrided, zsplits, s);
-  if (force == 264) return launch_gemm<256, 128, 2, 4, 32, 4, true>(p, a->x_kstrided, a->w_kstrided, zsplits, s);   // ping-pong, half-width tile: problems with <= 128 tiles of 256x256
-  if (force == 263) return launch_gemm<256, 256, 2, 4, 64, 2, true, true>(p, a->x_kstrided, a->w_kstrided, zsplits, s);   // 64-wide pipelined loop, staggered DMA issue (A/B)
-  if (force == 262) return launch_gemm<256, 256, 2, 4, 64, 2, true, false>(p, a->x_kstrided, a->w_kstrided, zsplits, s);   // pipelined, no stagger
+  if (force == 262) return launch_gemm<256, 256, 2, 4, 64, 2, true>(p, a->x_kstrided, a->w_kstrided, zsplits, s);
+  if (force == 264) return launch_gemm<256, 128, 2, 4, 32, 4, true>(p, a->x_kstrided, a->w_kstrided, zsplits, s);   // ping-pong, half-width tile
   if (big) return launch_gemm<256, 256, 2, 4, 32, 4, true>(p, a->x_kstrided, a->w_kstrided, zsplits, s);   // ping-pong loop
   if (mid) return launch_gemm<128, 128, 2, 2, 64, 2, true>(p, a->x_kstrided, a->w_kstrided, zsplits, s);
   return launch_gemm<64, 128, 2, 2, 64, 4>(p, a->x_kstrided, a->w_kstrided, zsplits, s);

@@ -204,8 +204,10 @@ def train_step(model, guide, optimizer, batch, args: TrainArgs, ready=None, towe
 
 class GraphedTrainStep:
     """The whole training step (all streams: compute, guide, weight gradients) captured once into a hipGraph and
-    replayed per batch — "HIP graphs instead of a tracing compiler".  A step is ~3300 kernel launches; eager Python
-    issues them in ~65-75 ms, which caps throughput once the GPU needs less than that.  Replay costs one launch.
+    replayed per batch — "HIP graphs instead of a tracing compiler".  A step is ~2400 kernel launches that eager Python
+    issues in ~31-37 ms; on this stack a replayed node costs about what an eager launch costs on the GPU side and the
+    graph runs its parallel branches less concurrently, so replay is slower than eager multi-stream launches while the GPU
+    needs ~74 ms per step: opt-in (`bench.py --graph`), kept working by tests/test_model_gpu.py.
 
     Capture-safety of the step: no host<->device sync inside it, LR / step counter / dropout counter live in device
     memory (lr_step kernel), every kernel is launched on torch's current stream (the capture stream or a side stream
@@ -235,8 +237,8 @@ class GraphedTrainStep:
 
 class FrozenTowerGraphs:
     """hipGraph replay for the two frozen, autograd-free, static-shape networks of the step (guide BART forward and
-    CLIP ViT forward): ~750 of the step's ~3300 launches become two graph launches on their side streams, which takes
-    ~15 ms per step off the Python launch path while the trainable network keeps eager multi-stream launches
+    CLIP ViT forward): ~430 of the step's launches become two graph launches on their side streams, which takes them off
+    the Python launch path while the trainable network keeps eager multi-stream launches
     (a single whole-step graph measured slower: hipGraph runs its parallel branches less concurrently than streams do).
 
     Static buffers: inputs are copied in on the tower's stream right before the replay; the outputs (`gh`, `img_cls`) are
