@@ -218,18 +218,30 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.f / l_tot;
-  if (qidx < p.Tq) {
-    bf16_t* orow = p.out + (long)b * p.bso + (long)qidx * p.ldo + hd * 64;
+  // Output through LDS: the accumulator layout gives every lane 8-byte pieces of ONE query row (row stride ldo), i.e. 512
+  // scattered 8-byte writes per wave-instruction — 14 us of a 63 us launch at S=512.  Each wave transposes its 32 x 64 tile
+  // in its own 4 KiB of the (now idle) K/V buffers and stores 128-byte row segments with 16-byte lanes.
+  {
+    char* ot = smem + wave * 4096;                     // [32 rows][128 B], 16-byte chunks XOR-swizzled by the row
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        u32x2 pk = {pack2bf(o[hb][4 * g] * inv, o[hb][4 * g + 1] * inv),
-                    pack2bf(o[hb][4 * g + 2] * inv, o[hb][4 * g + 3] * inv)};
-        *(u32x2*)(orow + hb * 32 + 8 * g + 4 * hh) = pk;
+        const u32x2 pk = {pack2bf(o[hb][4 * g] * inv, o[hb][4 * g + 1] * inv),
+                          pack2bf(o[hb][4 * g + 2] * inv, o[hb][4 * g + 3] * inv)};
+        const int c16 = hb * 4 + g;
+        *(u32x2*)(ot + ql * 128 + ((c16 ^ (ql & 7)) << 4) + 8 * hh) = pk;
       }
-    if (p.lse && hh == 0) p.lse[((long)b * p.H + hd) * p.Tq + qidx] = m_run * 0.6931471805599453f + __logf(l_tot);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // wave-local: written and read by the same wave
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (lane >> 3) + 8 * i, c16 = lane & 7;
+      const int qrow = q0 + row;
+      const u32x4 v = *(const u32x4*)(ot + row * 128 + ((c16 ^ (row & 7)) << 4));
+      if (qrow < p.Tq) *(u32x4*)(p.out + (long)b * p.bso + (long)qrow * p.ldo + hd * 64 + c16 * 8) = v;
+    }
   }
+  if (qidx < p.Tq && p.lse && hh == 0) p.lse[((long)b * p.H + hd) * p.Tq + qidx] = m_run * 0.6931471805599453f + __logf(l_tot);
 }
 
 // =================================================================================================
