@@ -102,6 +102,19 @@ __device__ __forceinline__ void fill_key_bias(float* kbias, const uint8_t* mask_
   }
 }
 
+
+// XCD-aware workgroup order.  The 1-D grid's workgroup L runs on XCD L % 8 and each XCD has its own L2; the nblk workgroups of
+// one (batch, head) all stream the same K/V (forward, dQ) or Q/dO (dK/dV) rows, so they are made consecutive ON ONE XCD —
+// with the natural (block, head, batch) order they land on different XCDs and every one of them fetches those rows from HBM
+// again (measured at S=512: 302 MB fetched for 100 MB of operands, L2 hit rate 10 %, the kernel HBM-bound at 5.3 TB/s).
+__device__ __forceinline__ void xcd_order(int nblk, int H, int nbh, int& blk, int& hd, int& b) {
+  const int L = blockIdx.x;
+  int bh;
+  if ((nbh & 7) == 0) { const int x = L & 7, j = L >> 3; bh = x + 8 * (j / nblk); blk = j % nblk; }
+  else { bh = L / nblk; blk = L % nblk; }
+  b = bh / H; hd = bh - b * H;
+}
+
 // =================================================================================================
 // forward:  S^T = K Q^T (keys in registers, query on the lane) -> online softmax -> O^T = V^T P^T
 // =================================================================================================
@@ -110,8 +123,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.z, hd = blockIdx.y;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  int b, hd, qblk;
+  xcd_order((p.Tq + 127) >> 7, p.H, p.B * p.H, qblk, hd, b);
+  const int q0 = qblk * 128 + wave * 32;
   const int ql = lane & 31, hh = lane >> 5;
   const int Tk_pad = (p.Tk + 63) & ~63;
   float* kbias = (float*)(smem + 4 * TILE_B);
@@ -124,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   __amdgpu_buffer_rsrc_t vs = make_rsrc(vb, p.Tk, p.ldv);
 
   int ntile = Tk_pad >> 6;
-  if (CAUSAL) ntile = min(ntile, (min(p.Tq, (int)blockIdx.x * 128 + 128) + 63) >> 6);
+  if (CAUSAL) ntile = min(ntile, (min(p.Tq, qblk * 128 + 128) + 63) >> 6);
 
   stage64(ks, smem, 0, p.Tk, p.ldk, wave, lane);
   stage64(vs, smem + TILE_B, 0, p.Tk, p.ldv, wave, lane);
@@ -280,8 +294,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.z, hd = blockIdx.y;
-  const int k0 = blockIdx.x * 128 + wave * 32;
+  int b, hd, kblk;
+  xcd_order((p.Tk + 127) >> 7, p.H, p.B * p.H, kblk, hd, b);
+  const int k0 = kblk * 128 + wave * 32;
   const int kl = lane & 31, hh = lane >> 5;
   const int kidx = k0 + kl;
   // LDS: 2 x {Q tile, dO tile} + 2 x {lse[64], delta[64]}
@@ -300,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnP p) {
 
   const int nq_tiles = (p.Tq + 63) >> 6;
   int t_begin = 0;
-  if (p.causal) t_begin = min(nq_tiles, (int)(blockIdx.x * 128) >> 6);   // queries before the first key see none of them
+  if (p.causal) t_begin = min(nq_tiles, (kblk * 128) >> 6);   // queries before the first key see none of them
 
   // K / V fragments of this wave's keys (B operand: element j = K[k][16*ks + 8*hh + j])
   bf16x8 kf[4], vf[4];
@@ -407,8 +422,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.z, hd = blockIdx.y;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  int b, hd, qblk;
+  xcd_order((p.Tq + 127) >> 7, p.H, p.B * p.H, qblk, hd, b);
+  const int q0 = qblk * 128 + wave * 32;
   const int ql = lane & 31, hh = lane >> 5;
   const int qidx = q0 + ql;
   const int Tk_pad = (p.Tk + 63) & ~63;
@@ -424,7 +440,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
   __amdgpu_buffer_rsrc_t dos = make_rsrc(dob, p.Tq, p.ldo);
 
   int ntile = Tk_pad >> 6;
-  if (p.causal) ntile = min(ntile, (min(p.Tq, (int)blockIdx.x * 128 + 128) + 63) >> 6);
+  if (p.causal) ntile = min(ntile, (min(p.Tq, qblk * 128 + 128) + 63) >> 6);
 
   stage64(ks, smem, 0, p.Tk, p.ldk, wave, lane);
   stage64(vs, smem + TILE_B, 0, p.Tk, p.ldv, wave, lane);
@@ -664,7 +680,7 @@ extern "C" int vacnic_attn_fwd(const vacnic_attn_fwd_args* a, void* stream) {
     return VACNIC_OK;
   }
   const int Tk_pad = (p.Tk + 63) & ~63;
-  dim3 grid((p.Tq + 127) / 128, p.H, p.B);
+  dim3 grid((unsigned)(((p.Tq + 127) / 128) * p.H * p.B));
   if (p.causal) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 4 * TILE_B + Tk_pad * 4, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 4 * TILE_B + Tk_pad * 4, (hipStream_t)stream, p);
   VLAUNCH_CHECK();
@@ -694,9 +710,9 @@ extern "C" int vacnic_attn_bwd(const vacnic_attn_bwd_args* a, void* stream) {
                      (const bf16_t*)a->dout, a->delta, p.B, p.H, p.Tq, p.ldo, (long)p.bso);
   VLAUNCH_CHECK();
   const int Tk_pad = (p.Tk + 63) & ~63;
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((p.Tk + 127) / 128, p.H, p.B), dim3(256), 4 * TILE_B + 2 * 128 * 4, s, p);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)(((p.Tk + 127) / 128) * p.H * p.B)), dim3(256), 4 * TILE_B + 2 * 128 * 4, s, p);
   VLAUNCH_CHECK();
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((p.Tq + 127) / 128, p.H, p.B), dim3(256), 4 * TILE_B + Tk_pad * 4, s, p);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(((p.Tq + 127) / 128) * p.H * p.B)), dim3(256), 4 * TILE_B + Tk_pad * 4, s, p);
   VLAUNCH_CHECK();
   return VACNIC_OK;
 }
