@@ -251,17 +251,25 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave % WM, wn = wave / WM;
 
-  // XCD-aware tile order: blocks b, b+8, ... share an XCD; give each XCD a contiguous run of tiles
-  // (bijective for any tile count), n fastest so neighbours reuse the same X panel in their L2.
+  // XCD-aware work order.  Workgroup L of the 1-D grid runs on XCD L % 8, each with its own 4 MiB L2.
+  //  * split-K launches (weight gradients): split z = L % nsplit, so one XCD (or nsplit/8 .. 8/nsplit of them) owns a whole
+  //    K-slice and every row of dY / X in it is fetched once — all tiles of a slice run concurrently on that XCD
+  //    (+2 % on the wgrad GEMMs; with the splits in blockIdx.z every XCD touched every K-slice).
+  //  * otherwise each XCD gets a contiguous run of tiles (bijective for any tile count), n fastest so neighbours reuse the
+  //    same X panel in their L2.  (Walking 4-column strips inside a run — an 8 x 4 block of tiles in flight instead of
+  //    2 x 16 — measured no gain: the 256 MiB memory-side cache already absorbs the W re-reads.)
   const int nt = p.tiles_m * p.tiles_n;
-  int bid = blockIdx.x;
-  {
+  int bid = blockIdx.x, zsplit = 0;
+  if (p.split_k > 1) {
+    zsplit = bid % p.split_k;
+    bid = bid / p.split_k;
+  } else {
     const int q = nt >> 3, r = nt & 7, xcd = bid & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
   const int tm = bid / p.tiles_n, tn = bid - tm * p.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int kbeg = blockIdx.z * p.k_per_split;
+  const int kbeg = zsplit * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);
   const int ntile = (p.debug & 2) ? 0 : (kend - kbeg + BKT - 1) / BKT;
 
@@ -469,7 +477,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
   constexpr int CLD = BN + 4;
   constexpr int PASSES = (BM + 63) / 64;
   const bool vec_ok = (p.ldo & 7) == 0;
-  const bool add_bias = blockIdx.z == 0;
+  const bool add_bias = zsplit == 0;
   float bia[8];
   // A pass stages 64 tile rows: RPWM = 64/WM rows from EACH wave row-group, so that every wave deposits in every pass (the
   // LDS store path has two halves, SIMDs {0,1} and {2,3}; a pass fed by the waves of one wm only ran it at half rate).
@@ -661,7 +669,7 @@ template <int BM, int BN, int WM, int WN, int BKT, int NSTAGE, bool PIPE = false
 int launch_gemm(const GemmP& p0, bool xks, bool wks, int zsplits, hipStream_t s) {
   GemmP p = p0;
   p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
-  dim3 grid(p.tiles_m * p.tiles_n, 1, zsplits), block(64 * WM * WN);
+  dim3 grid(p.tiles_m * p.tiles_n * zsplits), block(64 * WM * WN);
   constexpr size_t lds = NSTAGE * (BM + BN) * BKT * 2;
   static_assert(lds >= 64 * (BN + 4) * 4, "epilogue staging must fit in the operand buffers");
 #define VAC_LAUNCH(XK, WK)                                                                            \
