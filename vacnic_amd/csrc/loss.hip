@@ -133,24 +133,48 @@ __global__ void combine_losses_kernel(const float* ce_sum, const float* count, c
 __global__ __launch_bounds__(256) void colam_fwd_kernel(const bf16_t* __restrict__ hs, const bf16_t* __restrict__ hg,
                                                         const uint8_t* __restrict__ mask, float* __restrict__ cosv,
                                                         float* __restrict__ ps, float* __restrict__ pg, int T, int D) {
+  // one block per sample; a thread owns 8 consecutive columns (16-byte loads) and walks the T tokens 8 at a time with all 16
+  // loads of a batch in flight (the kernel is pure latency: 32 blocks, 8 MB; the token-at-a-time 2-byte version took 205 us)
   __shared__ float red[8];
+  __shared__ float wt[1024];                       // mask as 0/1 weights (T <= 1024 checked by the host)
   const int b = blockIdx.x;
   float cnt = 0.f;
-  for (int t = 0; t < T; ++t) cnt += mask[(long)b * T + t] ? 1.f : 0.f;
+  for (int t = threadIdx.x; t < T; t += 256) { const float w = mask[(long)b * T + t] ? 1.f : 0.f; wt[t] = w; cnt += w; }
+  cnt = block_sum(cnt, red);
+  __syncthreads();
   float dot = 0.f, na = 0.f, nb = 0.f;
-  for (int d = threadIdx.x; d < D; d += 256) {
-    float a = 0.f, g = 0.f;
-    for (int t = 0; t < T; ++t) {
-      if (mask[(long)b * T + t]) {
-        a += bf2f(hs[((long)b * T + t) * D + d]);
-        g += bf2f(hg[((long)b * T + t) * D + d]);
+  const bf16_t* sb = hs + (long)b * T * D;
+  const bf16_t* gb = hg + (long)b * T * D;
+  for (int c = threadIdx.x; c < (D >> 3); c += 256) {
+    float a[8], g[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a[j] = 0.f; g[j] = 0.f; }
+    for (int t0 = 0; t0 < T; t0 += 8) {
+      u32x4 ra[8], rg[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = min(t0 + u, T - 1);
+        ra[u] = *(const u32x4*)(sb + (long)t * D + c * 8);
+        rg[u] = *(const u32x4*)(gb + (long)t * D + c * 8);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float w = t0 + u < T ? wt[t0 + u] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          a[2 * i] += w * __uint_as_float(ra[u][i] << 16); a[2 * i + 1] += w * __uint_as_float(ra[u][i] & 0xffff0000u);
+          g[2 * i] += w * __uint_as_float(rg[u][i] << 16); g[2 * i + 1] += w * __uint_as_float(rg[u][i] & 0xffff0000u);
+        }
       }
     }
-    a = a / cnt; g = g / cnt;                 // cnt == 0 -> 0/0 = NaN
-    if (a != a) a = 1.f;                      // torch.nan_to_num(nan=1.0), TRAIN:181
-    if (g != g) g = 1.f;
-    ps[(long)b * D + d] = a; pg[(long)b * D + d] = g;
-    dot += a * g; na += a * a; nb += g * g;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float av = a[j] / cnt, gv = g[j] / cnt;      // cnt == 0 -> 0/0 = NaN
+      if (av != av) av = 1.f;                      // torch.nan_to_num(nan=1.0), TRAIN:181
+      if (gv != gv) gv = 1.f;
+      ps[(long)b * D + c * 8 + j] = av; pg[(long)b * D + c * 8 + j] = gv;
+      dot += av * gv; na += av * av; nb += gv * gv;
+    }
   }
   dot = block_sum(dot, red); na = block_sum(na, red); nb = block_sum(nb, red);
   if (threadIdx.x == 0) cosv[b] = dot / (sqrtf(na) * sqrtf(nb));
@@ -192,15 +216,34 @@ __global__ __launch_bounds__(256) void colam_bwd_kernel(const float* __restrict_
 // sim[i][n][j][f] = <names[i][n], faces[j][f]>; block per (i,n), waves stride over the B*F faces
 __global__ __launch_bounds__(256) void secla_sim_kernel(const bf16_t* __restrict__ faces, const float* __restrict__ names,
                                                         float* __restrict__ sim, int BF, int D) {
+  // block (name row, group of 16 faces): the name row sits in registers (16 floats per lane per 512 columns), every wave takes
+  // 4 faces with their 16-byte loads issued together.  (One block per name row walking all faces with 2-byte loads: 176 us.)
   const int row = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float* nm = names + (long)row * D;
-  for (int jf = wave; jf < BF; jf += 4) {
-    const bf16_t* fr = faces + (long)jf * D;
-    float s = 0.f;
-    for (int d = lane; d < D; d += 64) s += nm[d] * bf2f(fr[d]);
-    s = wave_sum(s);
-    if (lane == 0) sim[(long)row * BF + jf] = s;
+  const int nch = D >> 3;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  const int jf0 = blockIdx.y * 16 + wave * 4;
+  for (int c = lane; c < nch; c += 64) {
+    const f32x4 n0 = *(const f32x4*)(nm + c * 8), n1 = *(const f32x4*)(nm + c * 8 + 4);
+    u32x4 fr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int jf = min(jf0 + u, BF - 1);
+      fr[u] = *(const u32x4*)(faces + (long)jf * D + c * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float nlo = i < 2 ? n0[2 * i] : n1[2 * i - 4], nhi = i < 2 ? n0[2 * i + 1] : n1[2 * i - 3];
+        s[u] += nlo * __uint_as_float(fr[u][i] << 16) + nhi * __uint_as_float(fr[u][i] & 0xffff0000u);
+      }
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const float v = wave_sum(s[u]);
+    if (lane == 0 && jf0 + u < BF) sim[(long)row * BF + jf0 + u] = v;
   }
 }
 // logits1[i][j] = sum_n max_f sim[i][n][j][f] / N ; logits2[i][j] = sum_f max_n sim[j][n][i][f] / F
@@ -283,14 +326,54 @@ __global__ void secla_wsim_kernel(const float* __restrict__ sim, const float* __
 // dfaces[j][f][:] = sum_{i,n} wsim[i][n][j][f] * names[i][n][:]
 __global__ __launch_bounds__(256) void secla_dfaces_kernel(const float* __restrict__ wsim, const float* __restrict__ names,
                                                            bf16_t* __restrict__ dfaces, int BN, int BF, int D) {
+  // dfaces[jf] = sum_r wsim[r][jf] * names[r]; the routing weights are sparse (arg-max entries only), so the block first
+  // compacts the non-zero rows of its column into LDS and then streams just those name rows with 16-byte loads.
+  __shared__ int ridx[1024];
+  __shared__ float rw[1024];
+  __shared__ int nnz;
   const int jf = blockIdx.x;
-  for (int d = threadIdx.x; d < D; d += 256) {
-    float s = 0.f;
-    for (int r = 0; r < BN; ++r) {
-      const float w = wsim[(long)r * BF + jf];
-      if (w != 0.f) s += w * names[(long)r * D + d];
+  if (threadIdx.x < 64) {                          // ordered compaction by one wave (rows stay in increasing order: the sum
+    int count = 0;                                 // below adds in the same order as a plain walk -> deterministic)
+    const int lane = threadIdx.x;
+    for (int base = 0; base < BN; base += 64) {
+      const int r = base + lane;
+      const float w = r < BN ? wsim[(long)r * BF + jf] : 0.f;
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(w != 0.f);
+      const int pos = count + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+      if (w != 0.f && pos < 1024) { ridx[pos] = r; rw[pos] = w; }
+      count += __builtin_popcountll(m);
     }
-    dfaces[(long)jf * D + d] = f2bf(s);
+    if (lane == 0) nnz = count;
+  }
+  __syncthreads();
+  const int n = min(nnz, 1024);
+  for (int c = threadIdx.x; c < (D >> 2); c += 256) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (nnz <= 1024) {
+      for (int k0 = 0; k0 < n; k0 += 4) {
+        f32x4 v[4]; float w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int k = min(k0 + u, n - 1);
+          v[u] = *(const f32x4*)(names + (long)ridx[k] * D + c * 4);
+          w[u] = k0 + u < n ? rw[k] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] += w[u] * v[u][e];
+      }
+    } else {                                        // dense column (cannot happen with arg-max routing): plain walk
+      for (int r = 0; r < BN; ++r) {
+        const float w = wsim[(long)r * BF + jf];
+        if (w != 0.f) {
+          const f32x4 v = *(const f32x4*)(names + (long)r * D + c * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] += w * v[e];
+        }
+      }
+    }
+    *(u32x2*)(dfaces + (long)jf * D + c * 4) = (u32x2){pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3])};
   }
 }
 
@@ -341,6 +424,7 @@ extern "C" int vacnic_combine_losses(const float* ce_sum, const float* count, co
 extern "C" int vacnic_colam_fwd(const vacnic_colam_fwd_args* a, void* stream) {
   VCHECK(a && a->hs && a->hg && a->mask && a->loss && a->cos && a->pooled_s && a->pooled_g, VACNIC_BAD_SHAPE, "colam_fwd: null operand");
   VCHECK(a->B > 0 && a->T > 0 && a->D > 0, VACNIC_BAD_SHAPE, "colam_fwd: empty");
+  VCHECK(a->T <= 1024 && (a->D & 7) == 0 && aligned16(a->hs) && aligned16(a->hg), VACNIC_BAD_SHAPE, "colam_fwd: needs T <= 1024, D %% 8 == 0, 16-byte aligned states");
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(colam_fwd_kernel, dim3((unsigned)a->B), dim3(256), 0, s, (const bf16_t*)a->hs, (const bf16_t*)a->hg,
                      a->mask, a->cos, a->pooled_s, a->pooled_g, (int)a->T, (int)a->D);
@@ -362,9 +446,10 @@ extern "C" int vacnic_colam_bwd(const vacnic_colam_bwd_args* a, void* stream) {
 extern "C" int vacnic_secla_fwd(const vacnic_secla_fwd_args* a, void* stream) {
   VCHECK(a && a->faces && a->names && a->sim && a->logits1 && a->logits2 && a->loss, VACNIC_BAD_SHAPE, "secla_fwd: null operand");
   VCHECK(a->B > 0 && a->F > 0 && a->N > 0 && a->D > 0, VACNIC_BAD_SHAPE, "secla_fwd: empty");
+  VCHECK((a->D & 7) == 0 && aligned16(a->faces) && aligned16(a->names), VACNIC_BAD_SHAPE, "secla_fwd: needs D %% 8 == 0 and 16-byte aligned faces / names");
   hipStream_t s = (hipStream_t)stream;
   const int B = (int)a->B, F = (int)a->F, N = (int)a->N, D = (int)a->D;
-  hipLaunchKernelGGL(secla_sim_kernel, dim3(B * N), dim3(256), 0, s, (const bf16_t*)a->faces, a->names, a->sim, B * F, D);
+  hipLaunchKernelGGL(secla_sim_kernel, dim3(B * N, (B * F + 15) / 16), dim3(256), 0, s, (const bf16_t*)a->faces, a->names, a->sim, B * F, D);
   VLAUNCH_CHECK();
   hipLaunchKernelGGL(secla_logits_kernel, dim3((B * B + 255) / 256), dim3(256), 0, s, a->sim, a->logits1, a->logits2, B, F, N);
   VLAUNCH_CHECK();
