@@ -69,7 +69,22 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const void* __restrict__ lo
       m = nm;
     }
   } else {
-    for (int j = threadIdx.x; j < V; j += 256) {
+    // fp32 logits: 16-byte loads, two vectors in flight, one rescale per 8 values (the element-at-a-time loop was a serial
+    // chain of two exps per logit: 182 us for the 2048 x 50272 LM-head output)
+    const int nvec = (((uintptr_t)row & 15) == 0) ? (V >> 2) : 0;
+    for (int c = threadIdx.x; c < nvec; c += 512) {
+      const f32x4 a = ((const f32x4*)row)[c];
+      const bool two = c + 256 < nvec;
+      const f32x4 b = two ? ((const f32x4*)row)[c + 256] : (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      float cm = fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3])));
+      const float nm = fmaxf(m, cm);
+      float cs = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) cs += __expf(a[i] - nm) + __expf(b[i] - nm);      // exp(-inf) = 0 for the absent vector
+      s = s * __expf(m - nm) + cs;
+      m = nm;
+    }
+    for (int j = (nvec << 2) + threadIdx.x; j < V; j += 256) {
       const float v = ld_logit<F32>(row, j);
       const float nm = fmaxf(m, v);
       s = s * __expf(m - nm) + __expf(v - nm);
