@@ -225,13 +225,21 @@ int vacnic_name_embed_mean(const vacnic_name_embed_args* a, void* stream);
  *   p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
  * lr, step are read from device memory (graph-capture safe): hyper = {lr, step(as float)}.
  * Also refreshes the bf16 shadow and zeroes the gradient.  grad_scale multiplies g first
- * (1/world_size for DDP averaging).
+ * (1/world_size for DDP averaging).  clip_coef (may be NULL): device pointer to the clip_grad_norm_
+ * coefficient written by vacnic_grad_clip_coef; it multiplies g after grad_scale.
  */
 typedef struct {
   float* p; float* g; float* m; float* v; void* p_bf16; const float* hyper;
   int64_t n; float beta1, beta2, eps, weight_decay, grad_scale; int32_t zero_grad;
+  const float* clip_coef;
 } vacnic_adamw_args;
 int vacnic_adamw(const vacnic_adamw_args* a, void* stream);
+/* torch.nn.utils.clip_grad_norm_(model.parameters(), clip_norm) (TRAIN:365-366) over the flat gradient arena,
+ * without a host sync: out[0] <- min(1, max_norm / (||grad_scale*g||_2 + 1e-6)), out[1] <- that norm.
+ * partials: device scratch of >= 1024 floats.  Deterministic (fixed grid, no float atomics).  The gradient is not
+ * rewritten; pass `out` as vacnic_adamw_args.clip_coef and the scaling happens where AdamW reads g. */
+int vacnic_grad_clip_coef(const float* g, int64_t n, float grad_scale, float max_norm, float* partials,
+                          float* out, void* stream);
 /* get_linear_schedule_with_warmup on device (TRAIN:99-107): hyper[0] <- base_lr*lambda(k), hyper[1] <- k+1
  * where k = hyper[1] on entry = optimizer steps already taken.  Also increments *rng_counter (the device-side
  * dropout counter, may be NULL).  Call once before vacnic_adamw. */

@@ -386,6 +386,35 @@ def test_adamw_and_schedule(K):
     assert hyper[1].item() == 8.0
 
 
+@pytest.mark.parametrize("max_norm,world", [(0.1, 1), (1e4, 1), (0.5, 4)])
+def test_grad_clip_matches_torch_clip_grad_norm(K, max_norm, world):
+    """clip_grad_norm_ + AdamW (TRAIN:365-374) vs the fused device path: coefficient stays on the device, the gradient
+    arena is scaled where AdamW reads it.  max_norm=1e4: no clipping (coefficient clamps at 1)."""
+    n = 3 * 4096 * 17 + 12
+    p = rnd(n, dtype=torch.float32, seed=1); g = rnd(n, dtype=torch.float32, seed=2) * 3.0
+    m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda"); p16 = torch.empty(n, device="cuda", dtype=torch.bfloat16)
+    hyper = torch.zeros(2, device="cuda")
+    ref_p = torch.nn.Parameter(p.clone())
+    opt = torch.optim.AdamW([ref_p], lr=3e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    for step in range(3):
+        gg = g * (1.0 + 0.5 * step)                   # the arena holds the SUM over ranks; DDP hands clip_grad_norm_ the mean
+        ref_p.grad = gg.clone() / world
+        ref_norm = torch.nn.utils.clip_grad_norm_([ref_p], max_norm)
+        opt.step()
+        gbuf = gg.clone()
+        K.lr_step(hyper, 3e-5, 0.0, 1e9)
+        out = K.grad_clip_coef(gbuf, n, max_norm, grad_scale=1.0 / world)
+        out2 = K.grad_clip_coef(gbuf, n, max_norm, grad_scale=1.0 / world)
+        assert torch.equal(out, out2), "the norm must be bit-reproducible"
+        assert torch.equal(gbuf, gg), "the gradient arena is not rewritten by the norm pass"
+        K.adamw(p, gbuf, m, v, p16, hyper, n, grad_scale=1.0 / world, clip_coef=out)
+        assert abs(out[1].item() - ref_norm.item()) <= 1e-5 * ref_norm.item()
+        want = min(1.0, max_norm / (ref_norm.item() + 1e-6))
+        assert abs(out[0].item() - want) <= 1e-5 * want
+        assert (gbuf == 0).all()
+    close(p, ref_p.data, 1e-5, 1e-7, "clipped adamw params after 3 steps")
+
+
 # -------------------------------------------------------------------------------------------------- misc
 def test_misc(K):
     ids = torch.tensor([[0, 5, 6, 2, 1], [0, 9, 2, 1, 1]], device="cuda")

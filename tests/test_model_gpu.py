@@ -212,6 +212,43 @@ def test_train_steps_reduce_loss_and_match_oracle_adamw():
     assert (pad == 0).all(), "padded embedding rows stay exactly zero"
 
 
+def test_train_step_with_gradient_clipping():
+    """--no_clip_norm False --clip_norm 0.1 (TRAIN:365-366): the step's total gradient norm and the clipped AdamW update
+    against torch.nn.utils.clip_grad_norm_ + the oracle's AdamW on the same gradient."""
+    from oracle import vacnic_oracle as O
+    from vacnic_amd import streams, synthetic
+    from vacnic_amd.config import ClipVisionConfig
+    from vacnic_amd.training import FusedAdamW, TrainArgs, build_models, forward_losses, to_device, train_step
+    cfg = small_cfg(dropout=0.0, encoder_layers=1, decoder_layers=1)
+    vcfg = ClipVisionConfig(width=768, layers=1, patch_size=16, image_size=32, output_dim=64)
+    model, guide, _ = build_models(cfg, vcfg, init="synthetic", seed=0)
+    args = TrainArgs(num_training_steps=20, warmup_rate=0.0, lr_bart=1e-4, no_clip_norm=False, clip_norm=0.1)
+    opt = FusedAdamW(model.arena, lr=args.lr_bart, weight_decay=args.weight_decay, num_warmup_steps=0, num_training_steps=20)
+    batch = to_device(synthetic.make_batch(cfg, 3, S=32, T=12, F=3, seed=11, image_size=32), "cuda")
+    streams.enable(False)
+    model.train()
+    total, _, _ = forward_losses(model, guide, batch, args)
+    total.backward()
+    g = model.arena.grad.clone()
+    model.arena.grad.zero_()
+    p0 = model.arena.flat32.clone()
+    train_step(model, guide, opt, batch, args)                        # same batch, dropout 0: the same gradient
+    norm = g.double().norm().item()
+    assert norm > 0.1, "the case must actually clip"
+    assert abs(opt.clip[1].item() - norm) <= 2e-3 * norm             # split-K / LayerNorm atomics reorder fp32 sums between the two backward passes
+    coef = 0.1 / (norm + 1e-6)
+    assert abs(opt.clip[0].item() - coef) <= 2e-3 * coef
+    want, _, _ = O.adamw_step(p0.cpu(), (g * opt.clip[0]).cpu(), torch.zeros_like(p0).cpu(), torch.zeros_like(p0).cpu(), 1, 1e-4)
+    # first AdamW step is ~sign(g)*lr: compare where the gradient is well away from 0
+    sel = (g.abs() * coef > 1e-6).cpu()
+    err = (model.arena.flat32.cpu() - want)[sel].abs().max().item()
+    assert err <= 2e-6, err
+    args2 = TrainArgs(num_training_steps=20, warmup_rate=0.0, lr_bart=1e-4)       # and the default (no clipping) leaves no coefficient behind
+    opt2 = FusedAdamW(model.arena, lr=1e-4, num_warmup_steps=0, num_training_steps=20)
+    train_step(model, guide, opt2, batch, args2)
+    assert opt2.clip is None
+
+
 def test_checkpoint_resume_continues_the_run():
     """save after 2 steps, keep training 3 more; a differently-initialised model + optimizer restored from the
     checkpoint must continue with the same losses (weights, AdamW moments, LR position and dropout RNG all restored;

@@ -113,7 +113,7 @@ def run(args, batches=None):
     targs = TrainArgs(lr_bart=args.lr_bart, weight_decay=args.weight_decay, warmup_rate=args.warmup_rate,
                       num_training_steps=total_steps, margin=args.margin, alpha=args.alpha,
                       mapping_loss_weight=args.mapping_loss_weight, use_secla=args.use_secla, no_mapping=args.no_mapping,
-                      no_clip_norm=args.no_clip_norm)
+                      no_clip_norm=args.no_clip_norm, clip_norm=args.clip_norm)
     net = DistributedDataParallel(model, device_ids=[local], output_device=local) if world > 1 else model
     opt = FusedAdamW(model.arena, lr=args.lr_bart, weight_decay=args.weight_decay, num_warmup_steps=args.warmup_rate * total_steps,
                      num_training_steps=total_steps, world_size=world)

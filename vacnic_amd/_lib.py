@@ -104,7 +104,7 @@ NameEmbedArgs = _struct("vacnic_name_embed_args", [
 AdamwArgs = _struct("vacnic_adamw_args", [
     ("p", vp), ("g", vp), ("m", vp), ("v", vp), ("p_bf16", vp), ("hyper", vp),
     ("n", i64), ("beta1", f32), ("beta2", f32), ("eps", f32), ("weight_decay", f32), ("grad_scale", f32),
-    ("zero_grad", i32)])
+    ("zero_grad", i32), ("clip_coef", vp)])
 
 # symbol -> argtypes.  EVERY function include/vacnic_hip.h declares must appear here
 # (tests/test_abi.py parses the header and checks both directions).
@@ -120,6 +120,7 @@ _STRUCT_FNS = {
 _PLAIN_FNS = {
     "vacnic_combine_losses": [vp, vp, vp, vp, f32, f32, vp, vp],
     "vacnic_lr_step": [vp, f32, f32, f32, vp, vp],
+    "vacnic_grad_clip_coef": [vp, i64, f32, f32, vp, vp, vp],
     "vacnic_cast_f32_bf16": [vp, vp, i64, vp],
     "vacnic_cast_bf16_f32": [vp, vp, i64, vp],
     "vacnic_copy2d_bf16": [vp, vp, i64, i64, i64, i64, i32, vp],

@@ -22,8 +22,10 @@ __global__ void lr_step_kernel(float* hyper, float base_lr, float warmup, float 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, bf16_t* __restrict__ pb,
                                                     const float* __restrict__ hyper, long n4, float b1, float b2,
-                                                    float eps, float wd, float gscale, int zero_grad) {
+                                                    float eps, float wd, float gscale, int zero_grad,
+                                                    const float* __restrict__ clip) {
   const float lr = hyper[0], t = hyper[1];
+  if (clip) gscale *= clip[0];                  // clip_grad_norm_'s coefficient, computed on device by grad_clip_coef
   const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
   const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2), decay = 1.f - lr * wd;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -40,6 +42,39 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
     ((f32x4*)p)[i] = pv; ((f32x4*)m)[i] = mv; ((f32x4*)v)[i] = vv;
     if (zero_grad) ((f32x4*)g)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (pb) ((u32x2*)pb)[i] = (u32x2){pack2bf(pv[0], pv[1]), pack2bf(pv[2], pv[3])};
+  }
+}
+
+// clip_grad_norm_ (TRAIN:365-366), pass 1: fixed-grid partial sums of (g*gscale)^2 — fixed grid + fixed
+// per-thread order + a fixed-shape tree, so the norm is bit-reproducible run to run (no float atomics).
+constexpr int kNormBlocks = 1024;
+__global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* __restrict__ g, long n4, float gscale,
+                                                         float* __restrict__ partials) {
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 gv = ((const f32x4*)g)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float x = gv[e] * gscale; acc = fmaf(x, x, acc); }
+  }
+  __shared__ float red[4];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+// pass 2 (one workgroup): out[0] = min(1, max_norm / (||g|| + 1e-6)), out[1] = ||g||   (torch.nn.utils.clip_grad_norm_)
+__global__ __launch_bounds__(256) void grad_clip_coef_kernel(const float* __restrict__ partials, int nparts, float max_norm,
+                                                             float* __restrict__ out) {
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) acc += partials[i];
+  __shared__ float red[4];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+    out[0] = fminf(1.f, max_norm / (norm + 1e-6f));
+    out[1] = norm;
   }
 }
 
@@ -79,7 +114,19 @@ extern "C" int vacnic_adamw(const vacnic_adamw_args* a, void* stream) {
   const long n4 = a->n >> 2;
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n4)), dim3(256), 0, (hipStream_t)stream, a->p, a->g, a->m, a->v,
                      (bf16_t*)a->p_bf16, a->hyper, n4, a->beta1, a->beta2, a->eps, a->weight_decay, a->grad_scale,
-                     a->zero_grad);
+                     a->zero_grad, a->clip_coef);
+  VLAUNCH_CHECK();
+  return VACNIC_OK;
+}
+
+extern "C" int vacnic_grad_clip_coef(const float* g, int64_t n, float grad_scale, float max_norm, float* partials,
+                                     float* out, void* stream) {
+  VCHECK(g && partials && out, VACNIC_BAD_SHAPE, "grad_clip_coef: null operand");
+  VCHECK((n & 3) == 0 && aligned16(g), VACNIC_BAD_SHAPE, "grad_clip_coef: arena must be 16-byte aligned, n=%ld a multiple of 4", (long)n);
+  VCHECK(max_norm > 0.f, VACNIC_BAD_SHAPE, "grad_clip_coef: max_norm must be > 0");
+  hipLaunchKernelGGL(grad_sumsq_kernel, dim3(kNormBlocks), dim3(256), 0, (hipStream_t)stream, g, (long)(n >> 2), grad_scale, partials);
+  VLAUNCH_CHECK();
+  hipLaunchKernelGGL(grad_clip_coef_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, kNormBlocks, max_norm, out);
   VLAUNCH_CHECK();
   return VACNIC_OK;
 }

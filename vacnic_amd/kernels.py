@@ -276,10 +276,22 @@ def lr_step(hyper, base_lr, warmup, total, rng_counter=None):
     call("vacnic_lr_step", hyper.data_ptr(), base_lr, float(warmup), float(total), _p(rng_counter), _stream())
 
 
-def adamw(p, g, m, v, p16, hyper, n, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, grad_scale=1.0, zero_grad=True):
+def adamw(p, g, m, v, p16, hyper, n, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, grad_scale=1.0, zero_grad=True,
+          clip_coef=None):
     call_struct("vacnic_adamw", stream=_stream(), p=_p(p), g=_p(g), m=_p(m), v=_p(v), p_bf16=_p(p16), hyper=_p(hyper),
                 n=n, beta1=beta1, beta2=beta2, eps=eps, weight_decay=weight_decay, grad_scale=grad_scale,
-                zero_grad=int(zero_grad))
+                zero_grad=int(zero_grad), clip_coef=_p(clip_coef))
+
+
+def grad_clip_coef(g, n, max_norm, grad_scale=1.0, partials=None, out=None):
+    """clip_grad_norm_ (TRAIN:365-366) on device: returns the fp32 pair {clip coefficient, total norm}."""
+    if partials is None:
+        partials = torch.empty(1024, device=g.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty(2, device=g.device, dtype=torch.float32)
+    assert g.dtype == torch.float32 and partials.numel() >= 1024 and out.numel() >= 2
+    call("vacnic_grad_clip_coef", _p(g), n, grad_scale, max_norm, _p(partials), _p(out), _stream())
+    return out
 
 
 # ------------------------------------------------------------------------------------------------- misc

@@ -29,6 +29,7 @@ class TrainArgs:
     use_secla: bool = True
     no_mapping: bool = False
     no_clip_norm: bool = True
+    clip_norm: float = 0.1
     prompt_mlp_type: str = "clipcap"
 
 
@@ -44,12 +45,23 @@ class FusedAdamW:
         self.warmup, self.total = float(num_warmup_steps), float(num_training_steps)
         self.world = world_size
         self.hyper = torch.zeros(2, device=arena.device, dtype=torch.float32)      # {lr, step}
+        self.clip = None                  # {clip coefficient, total grad norm} of the last clipped step (device)
+        self._clip_scratch = None
 
-    def step(self):
+    def step(self, clip_norm=None):
+        """clip_norm: max total gradient norm (torch.nn.utils.clip_grad_norm_, TRAIN:365-366) or None.  The norm is taken
+        over the averaged gradient (after the 1/world scaling), as DDP hands it to clip_grad_norm_ in the reference; the
+        coefficient stays in device memory and is applied where the AdamW kernel reads the gradient."""
         a = self.arena
         K.lr_step(self.hyper, self.lr, self.warmup, self.total, ops.Rng.device_counter())   # also advances the dropout counter
+        clip = None
+        if clip_norm is not None:
+            if self.clip is None:
+                self.clip = torch.zeros(2, device=a.device, dtype=torch.float32)
+                self._clip_scratch = torch.empty(1024, device=a.device, dtype=torch.float32)
+            clip = K.grad_clip_coef(a.grad, a.n, float(clip_norm), 1.0 / self.world, self._clip_scratch, self.clip)
         K.adamw(a.flat32, a.grad, a.exp_avg, a.exp_avg_sq, a.flat16, self.hyper, a.n, self.betas[0], self.betas[1],
-                self.eps, self.wd, grad_scale=1.0 / self.world, zero_grad=True)
+                self.eps, self.wd, grad_scale=1.0 / self.world, zero_grad=True, clip_coef=clip)
 
     def zero_grad(self):
         pass            # fused into step(): the AdamW kernel clears the gradient arena it just consumed
@@ -195,9 +207,7 @@ def train_step(model, guide, optimizer, batch, args: TrainArgs, ready=None, towe
     streams.join_all()                       # weight-gradient side stream -> compute stream
     if isinstance(model, DistributedDataParallel):
         model.reduce_gradients()
-    if not args.no_clip_norm:
-        raise NotImplementedError("clip_grad_norm_ (TRAIN:365-366): shipped scripts pass --no_clip_norm True")
-    optimizer.step()
+    optimizer.step(clip_norm=None if args.no_clip_norm else args.clip_norm)      # TRAIN:365-366
     optimizer.zero_grad()
     return out4
 
