@@ -63,12 +63,14 @@ def bart_config(cfg: VacnicConfig):
 
 def build_ref_model(mod, cfg: VacnicConfig, sd):
     kw = dict(enc_fusion_layer=list(cfg.enc_fusion_layer), dim_common=cfg.dim_common, img_size=768,
-              prompt_mlp_type="clipcap", prompt_size=cfg.prompt_size, clip_model=None, max_ner_type_len=cfg.max_ner_type_len,
+              prompt_mlp_type=cfg.prompt_mlp_type, prompt_size=cfg.prompt_size, clip_model=None, max_ner_type_len=cfg.max_ner_type_len,
               max_ner_type_len_gt=cfg.max_ner_type_len_gt)
     if mod.__name__ == MFULL_MOD:
         kw["only_image"] = cfg.only_image
+    if cfg.prompt_mlp_type == "mlp":
+        kw["map_size"] = list(cfg.map_size)
     m = mod.BartForMultiModalGeneration(bart_config(cfg), **kw)
-    if cfg.clip_width != 768:
+    if cfg.clip_width != 768 and cfg.prompt_mlp_type == "clipcap":
         # documented one-line deviation (SURVEY "facts"): the 768 at MFULL:1136 is the CLIP width
         P = cfg.prompt_size
         m.model.encoder.prompt_mlp = mod.MLPClipCap((cfg.clip_width, (768 * P) // 2, 768 * P))
@@ -91,6 +93,14 @@ def small_cfg(**kw):
     return VacnicConfig(**base)
 
 
+def mlp_cfg():
+    """--prompt_mlp_type mlp --map_size 12 32 16 8 (MFULL:76-108,1138): 12 patch tokens (not a multiple of 8, like ViT-B/16's 196)
+    mixed down to an 8-token prompt, then visual_map 768 -> 1024."""
+    return small_cfg(d_model=1024, encoder_layers=1, decoder_layers=1, encoder_attention_heads=16, decoder_attention_heads=16,
+                     encoder_ffn_dim=2048, decoder_ffn_dim=2048, dim_common=1024, clip_width=768, prompt_mlp_type="mlp",
+                     map_size=[12, 32, 16, 8])
+
+
 def slices(t, n=4096):
     """deterministic strided sample of a tensor + its full-tensor checksum."""
     f = t.detach().reshape(-1).double()
@@ -110,7 +120,7 @@ def run_full_case(name, mfull, train, BatchSoftmax, cfg, B, S, T, F, grads=True)
     src_mask = train.create_src_mask_bart(src)
     face_mask = train.create_src_mask_bart(batch["face_emb"][:, :, -1])
     name_mask = train.create_src_mask_bart(batch["names_art_ids"])
-    img_cls = synthetic._normal("img_cls", (B, cfg.clip_width), 1.0, 3)
+    img_cls = synthetic.image_features(cfg, B)            # CLS vector (clipcap) or patch tokens (--prompt_mlp_type mlp)
     for p in model.parameters():
         p.requires_grad_(True)
     out = model(input_ids=src, attention_mask=src_mask, decoder_input_ids=tgt_in, image_features=img_cls,
@@ -150,6 +160,7 @@ def run_full_case(name, mfull, train, BatchSoftmax, cfg, B, S, T, F, grads=True)
                       "model.encoder.layers.0.ner_map_up.weight", "model.encoder.layers.0._face_up.weight",
                       "model.encoder.layers.0.cross_attn_img_ner.k_proj.weight", "model.encoder.layers.1.fc1.weight",
                       "model.encoder.prompt_mlp.model.0.weight", "model.encoder.prompt_mlp.model.2.bias",
+                      "model.encoder.prompt_mlp.model.4.weight", "model.encoder.prompt_mlp.model.4.bias",
                       "model.encoder._linear_1.weight", "model.encoder.embed_tokens_ner.weight",
                       "model.encoder.embed_positions.weight", "model.encoder.layernorm_embedding.weight",
                       "model.decoder.layers.1.encoder_attn.v_proj.weight", "model.decoder.layers.0.fc2.bias",
@@ -346,6 +357,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "collate":
         run_collate()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "mlp":
+        run_full_case("mfull_mlp_d1024", mfull, train, BatchSoftmax, mlp_cfg(), B=2, S=40, T=10, F=2)
+        return
     run_collate()
     run_helpers(train, BatchSoftmax)
     run_generate_case(mfull, train)
@@ -356,6 +370,7 @@ def main():
                             decoder_attention_heads=16, encoder_ffn_dim=2048, decoder_ffn_dim=2048, dim_common=1024,
                             clip_width=1024), B=2, S=40, T=10, F=2)
     run_mvis_case("mvis_d768", mvis, train, small_cfg(only_image=True, enc_fusion_layer=[0, 1]), B=2, S=32, T=8)
+    run_full_case("mfull_mlp_d1024", mfull, train, BatchSoftmax, mlp_cfg(), B=2, S=40, T=10, F=2)
 
 
 if __name__ == "__main__":

@@ -136,11 +136,23 @@ def encoder(sd, cfg, input_ids, attention_mask, image_features, name_ids=None, n
         fm = torch.cat((face_mask, name_mask), dim=1)                                                     # :1262
         face_name_mask = expand_mask(fm, tgt_len=cfg.max_ner_type_len)                                    # :1264
         face = linear(sd, e + "._linear_1", face_features)                                                # :1269
-    img = linear(sd, e + ".prompt_mlp.model.2", torch.tanh(linear(sd, e + ".prompt_mlp.model.0", image_features)))
-    img = img.reshape(B, cfg.prompt_size, 768)                                                            # :1274-1276
+    if cfg.prompt_mlp_type == "mlp":
+        # MLP.forward, MFULL:76-108: the [B, tokens, width] features are RESHAPED (not transposed) to [B, width, tokens], Linear(+Tanh)
+        # runs over the last axis, and the result is reshaped back to [B, map_size[-1], width]
+        _, feat, hid = image_features.shape
+        x = image_features.reshape(B, hid, feat)
+        nl = len(cfg.map_size) - 1
+        for i in range(nl):
+            x = linear(sd, f"{e}.prompt_mlp.model.{2 * i}", x)
+            if i < nl - 1:
+                x = torch.tanh(x)
+        img = x.reshape(B, cfg.map_size[-1], hid)                                                         # :1274
+    else:
+        img = linear(sd, e + ".prompt_mlp.model.2", torch.tanh(linear(sd, e + ".prompt_mlp.model.0", image_features)))
+        img = img.reshape(B, cfg.prompt_size, 768)                                                        # :1274-1276
     if cfg.d_model == 1024:
         img = linear(sd, e + ".visual_map", img)                                                          # :1277-1278
-    n_kv = cfg.prompt_size + (0 if cfg.only_image else cfg.max_ner_type_len_gt)
+    n_kv = cfg.prompt_len + (0 if cfg.only_image else cfg.max_ner_type_len_gt)
     img_ner_mask = expand_mask(torch.ones(B, n_kv), tgt_len=S)                                            # :1286-1296
     attn_mask = expand_mask(attention_mask)
     for i in range(cfg.encoder_layers):

@@ -27,8 +27,14 @@ def test_config_validation():
     assert c1.only_image and v1.tokens == 50 and c1.encoder_layers == 6
     with pytest.raises(ValueError):
         VacnicConfig(d_model=512, encoder_attention_heads=8).validate()
-    with pytest.raises(NotImplementedError):
-        VacnicConfig(prompt_mlp_type="mlp").validate()
+    with pytest.raises(ValueError, match="map_size"):
+        VacnicConfig(prompt_mlp_type="mlp", clip_width=768).validate()
+    with pytest.raises(ValueError, match="multiples of 8"):
+        VacnicConfig(prompt_mlp_type="mlp", clip_width=768, map_size=[196, 250, 16]).validate()
+    with pytest.raises(ValueError, match="768-wide"):
+        VacnicConfig(prompt_mlp_type="mlp", clip_width=1024, map_size=[256, 64, 16]).validate()
+    c2 = VacnicConfig(prompt_mlp_type="mlp", clip_width=768, map_size=[196, 256, 64, 16]).validate()
+    assert c2.prompt_len == 16 and VacnicConfig().prompt_len == 20
 
 
 def test_synthetic_batch_contract():
@@ -115,8 +121,10 @@ def test_unsupported_flags_raise():
     from vacnic_amd.models.mmbart import BartAttention, BartForMultiModalGeneration
     with pytest.raises(ValueError, match="divisible"):
         BartAttention(100, 3)
-    with pytest.raises(NotImplementedError):
-        BartForMultiModalGeneration(small_cfg(), enc_fusion_layer=[0], dim_common=768, prompt_mlp_type="mlp")
+    m = BartForMultiModalGeneration(small_cfg(), enc_fusion_layer=[0], dim_common=768, prompt_mlp_type="mlp", map_size=[196, 256, 64, 16])
+    names = [n for n, _ in m.named_parameters() if "prompt_mlp" in n]          # MFULL:76-108: Linear at Sequential slots 0, 2, 4
+    assert names == [f"model.encoder.prompt_mlp.model.{i}.{w}" for i in (0, 2, 4) for w in ("weight", "bias")]
+    assert tuple(m.model.encoder.prompt_mlp.model[0].weight.shape) == (256, 196)
     with pytest.raises(NotImplementedError):
         BartForMultiModalGeneration(small_cfg(), enc_fusion_layer=[0], dim_common=768, init_attn_weight=True)
 

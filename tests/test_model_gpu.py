@@ -27,6 +27,10 @@ CASES = {
     "mfull_d768": (dict(), dict(B=3, S=48, T=12, F=3)),
     "mfull_d1024": (dict(d_model=1024, encoder_layers=1, decoder_layers=1, encoder_attention_heads=16, decoder_attention_heads=16,
                          encoder_ffn_dim=2048, decoder_ffn_dim=2048, dim_common=1024, clip_width=1024), dict(B=2, S=40, T=10, F=2)),
+    # --prompt_mlp_type mlp --map_size 12 32 16 8 (MFULL:76-108,1138): 12 patch tokens (ragged K, like ViT-B/16's 196) -> 8-token prompt
+    "mfull_mlp_d1024": (dict(d_model=1024, encoder_layers=1, decoder_layers=1, encoder_attention_heads=16, decoder_attention_heads=16,
+                             encoder_ffn_dim=2048, decoder_ffn_dim=2048, dim_common=1024, clip_width=768, prompt_mlp_type="mlp",
+                             map_size=[12, 32, 16, 8]), dict(B=2, S=40, T=10, F=2)),
 }
 
 
@@ -57,7 +61,7 @@ def test_full_model_matches_oracle_and_reference_golden(case, side_streams):
     model.eval()
     B, S, T, F = dims["B"], dims["S"], dims["T"], dims["F"]
     batch = synthetic.make_batch(cfg, B, S=S, T=T, F=F, seed=7, image_size=32)
-    img_cls = synthetic._normal("img_cls", (B, cfg.clip_width), 1.0, 3)
+    img_cls = synthetic.image_features(cfg, B)
     dev = {k: v.cuda() for k, v in batch.items()}
     src, tgt = dev["article_ids"], dev["caption_ids"]
     src_mask, _ = K.prep_ids(src, 1)
@@ -210,6 +214,39 @@ def test_train_steps_reduce_loss_and_match_oracle_adamw():
     assert (sh - model.arena.flat32).abs().max().item() <= 4e-3 * model.arena.flat32.abs().max().item() + 1e-6
     pad = model.emb16_pad[model.V:]
     assert (pad == 0).all(), "padded embedding rows stay exactly zero"
+
+
+def test_train_and_generate_with_token_mixing_prompt_mlp():
+    """--prompt_mlp_type mlp end to end: the ViT tower hands its ln_post patch tokens (not the CLS vector) to the model, in the
+    eager step, in the tower hipGraphs and in generate (the reference trainers branch the same way at each model call)."""
+    from vacnic_amd import streams, synthetic
+    from vacnic_amd.config import ClipVisionConfig
+    from vacnic_amd.generate import generate
+    from vacnic_amd.models.clip_vit import extract_clip_img_feat
+    from vacnic_amd.training import FrozenTowerGraphs, FusedAdamW, TrainArgs, build_models, to_device, train_step
+    from vacnic_amd import kernels as K
+    cfg = small_cfg(dropout=0.1, encoder_layers=1, decoder_layers=1, prompt_mlp_type="mlp", map_size=[4, 16, 8]).validate()
+    vcfg = ClipVisionConfig(width=768, layers=1, patch_size=16, image_size=32, output_dim=64)       # 2x2 patches -> 4 tokens
+    model, guide, clip = build_models(cfg, vcfg, init="synthetic", seed=0)
+    args = TrainArgs(num_training_steps=20, warmup_rate=0.1, lr_bart=1e-4, prompt_mlp_type="mlp")
+    opt = FusedAdamW(model.arena, lr=args.lr_bart, weight_decay=args.weight_decay, num_warmup_steps=2, num_training_steps=20)
+    batch = to_device(synthetic.make_batch(cfg, 4, S=32, T=12, F=3, seed=11, image_size=32), "cuda")
+    streams.enable(True)
+    towers = FrozenTowerGraphs(model, guide, batch)
+    assert tuple(towers.img_cls.shape) == (4, 4, 768)
+    losses = [train_step(model, guide, opt, batch, args, towers=towers).tolist() for _ in range(5)]
+    streams.join_all(); torch.cuda.synchronize()
+    streams.enable(False)
+    eager = [train_step(model, guide, opt, batch, args).tolist() for _ in range(2)]
+    assert np.isfinite(losses).all() and np.isfinite(eager).all()
+    assert eager[-1][1] < losses[0][1], (losses[0], eager[-1])
+    model.eval()
+    feats, _ = extract_clip_img_feat(clip, batch["img_tensor"])
+    mask, _ = K.prep_ids(batch["article_ids"], 1)
+    nmask, _ = K.prep_ids(batch["names_art_ids"], 1)
+    seq = generate(model, batch["article_ids"], mask, num_beams=3, max_length=8, image_features=feats, face_features=batch["face_emb"],
+                   face_mask=K.face_mask(batch["face_emb"]), name_ids=batch["names_art_ids"], name_mask=nmask)
+    assert seq.shape[0] == 4 and seq.shape[1] <= 8 and (seq[:, 0] == 2).all()
 
 
 def test_train_step_with_gradient_clipping():

@@ -28,6 +28,10 @@ CASES = {
     "mfull_d1024": (small_cfg(d_model=1024, encoder_layers=1, decoder_layers=1, encoder_attention_heads=16,
                               decoder_attention_heads=16, encoder_ffn_dim=2048, decoder_ffn_dim=2048, dim_common=1024,
                               clip_width=1024), dict(B=2, S=40, T=10, F=2)),
+    # --prompt_mlp_type mlp --map_size 12 32 16 8 (MFULL:76-108): token-mixing prompt MLP over patch tokens, then visual_map
+    "mfull_mlp_d1024": (small_cfg(d_model=1024, encoder_layers=1, decoder_layers=1, encoder_attention_heads=16,
+                                  decoder_attention_heads=16, encoder_ffn_dim=2048, decoder_ffn_dim=2048, dim_common=1024,
+                                  clip_width=768, prompt_mlp_type="mlp", map_size=[12, 32, 16, 8]), dict(B=2, S=40, T=10, F=2)),
 }
 
 
@@ -47,7 +51,7 @@ def full_case_inputs(cfg, B, S, T, F):
     sd = synthetic.make_state_dict(synthetic.mmbart_param_shapes(cfg), seed=1)
     sd_g = synthetic.make_state_dict(synthetic.guide_bart_param_shapes(cfg), seed=2)
     batch = synthetic.make_batch(cfg, B, S=S, T=T, F=F, seed=7, image_size=32)
-    img_cls = synthetic._normal("img_cls", (B, cfg.clip_width), 1.0, 3)
+    img_cls = synthetic.image_features(cfg, B)
     return sd, sd_g, batch, img_cls
 
 

@@ -105,7 +105,7 @@ def run(args, batches=None):
     vkw = CLIP[args.clip_type]
     cfg = VacnicConfig(enc_fusion_layer=list(args.enc_fusion_layer or []), dim_common=args.dim_common, prompt_size=args.prompt_size,
                        max_ner_type_len=args.max_ner_type_len, max_ner_type_len_gt=args.max_ner_type_len_gt,
-                       only_image=args.only_image, clip_width=vkw["width"], prompt_mlp_type=args.prompt_mlp_type,
+                       only_image=args.only_image, clip_width=vkw["width"], prompt_mlp_type=args.prompt_mlp_type, map_size=args.map_size,
                        **PLM[args.plm_type]).validate()
     vcfg = ClipVisionConfig(**vkw)
     model, guide, _ = build_models(cfg, vcfg, device="cuda", seed=int(args.seed) % (2 ** 31), init="device")

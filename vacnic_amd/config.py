@@ -31,6 +31,7 @@ class VacnicConfig:
     dim_common: int = 1024
     prompt_mlp_type: str = "clipcap"
     prompt_size: int = 20
+    map_size: List[int] = None         # --prompt_mlp_type mlp: [n_patch_tokens, h1, ..., prompt_len] (TRAIN `--map_size`, MFULL:1138)
     max_ner_type_len: int = 80
     max_ner_type_len_gt: int = 20
     only_image: bool = False
@@ -41,13 +42,27 @@ class VacnicConfig:
     def head_dim(self):
         return self.d_model // self.encoder_attention_heads
 
+    @property
+    def prompt_len(self):
+        """visual-prompt tokens entering the encoder: prompt_size (ClipCap MLP) or map_size[-1] (token-mixing MLP)."""
+        return self.prompt_size if self.prompt_mlp_type == "clipcap" else int(self.map_size[-1])
+
     def validate(self):
         if self.d_model not in (768, 1024):
             raise ValueError("d_model must be 768 or 1024 (prompt is reshaped to [B,P,768], MFULL:1143-1144,1275-1278)")
         if self.d_model % self.encoder_attention_heads or self.d_model // self.encoder_attention_heads != 64:
             raise ValueError("head_dim must be 64 (bart-base 768/12, bart-large 1024/16)")
-        if self.prompt_mlp_type != "clipcap":
-            raise NotImplementedError("--prompt_mlp_type mlp (MFULL:76-108) is out of scope (SURVEY §2 row 19)")
+        if self.prompt_mlp_type not in ("clipcap", "mlp"):
+            raise ValueError(f"prompt_mlp_type must be 'clipcap' or 'mlp', got {self.prompt_mlp_type!r}")
+        if self.prompt_mlp_type == "mlp":
+            ms = self.map_size
+            if not ms or len(ms) < 2 or any(int(m) <= 0 for m in ms):
+                raise ValueError("--prompt_mlp_type mlp needs --map_size n_tokens h1 ... prompt_len (MFULL:76-108,1138)")
+            if any(int(m) % 8 for m in ms[1:]):
+                raise ValueError("map_size[1:] must be multiples of 8 (16-byte rows for the GEMMs); map_size[0] is free")
+            if self.clip_width != 768:
+                raise ValueError("prompt_mlp_type mlp keeps the ViT width as the prompt width: it needs a 768-wide CLIP tower "
+                                 "(MFULL:1143,1277 feed it to Linear(768, 1024))")
         if not self.only_image and self.dim_common != self.d_model:
             raise ValueError("dim_common must equal d_model: face states are concatenated with name states (MFULL:668)")
         return self

@@ -44,6 +44,33 @@ class MLPClipCap(nn.Module):
         return ops.mlp2(x, self.model[0].weight, self.s0, self.s2, act="tanh")
 
 
+class MLP(nn.Module):
+    """MFULL:76-108 (`--prompt_mlp_type mlp`): a token-mixing MLP over the ViT patch tokens.  The reference *reshapes*
+    (not transposes) [B, n_tokens, width] to [B, width, n_tokens], runs Linear(+Tanh) over the last axis down to
+    sizes[-1], and reshapes back to [B, sizes[-1], width]; parameter names model.0 / model.2 / model.4 ..."""
+
+    def __init__(self, sizes, hidden_size=768, bias=True):
+        super().__init__()
+        layers = []
+        for i in range(len(sizes) - 1):
+            layers.append(nn.Linear(sizes[i], sizes[i + 1], bias=bias))
+            if i < len(sizes) - 2:
+                layers.append(nn.Tanh())
+        self.sizes = list(sizes)
+        self.model = nn.Sequential(*layers)
+
+    def bind_arena(self, arena):
+        self.specs = [_spec(m, arena.trainable) for m in self.model if isinstance(m, nn.Linear)]
+
+    def forward(self, x):
+        if x.dim() != 3 or x.shape[1] != self.sizes[0]:
+            raise ValueError(f"prompt MLP expects image_features [B, {self.sizes[0]}, width] (ln_post patch tokens, TRAIN:220-240), "
+                             f"got {tuple(x.shape)}")
+        B, feat, hidden = x.shape
+        y = ops.mlp_chain(x.reshape(B * hidden, feat), self.model[0].weight, self.specs, act="tanh")
+        return y.reshape(B, self.sizes[-1], hidden)
+
+
 class BartLearnedPositionalEmbedding(nn.Embedding):
     """MFULL:401-418: table has 2 extra rows; position t reads row t+2 (done inside the embed kernels)."""
 
@@ -255,9 +282,11 @@ class BartEncoder(nn.Module):
                                      for _ in range(config.encoder_layers)])
         self.layernorm_embedding = nn.LayerNorm(d)
         self.fusion_layer = list(fusion_layer or [])
-        if prompt_mlp_type != "clipcap":
-            raise NotImplementedError("prompt_mlp_type='mlp' (MFULL:76-108) is out of scope; every BASELINE config uses clipcap")
-        self.prompt_mlp = MLPClipCap((config.clip_width, (768 * prompt_size) // 2, 768 * prompt_size))   # MFULL:1136 (768 -> clip_width)
+        if prompt_mlp_type == "clipcap":
+            self.prompt_mlp = MLPClipCap((config.clip_width, (768 * prompt_size) // 2, 768 * prompt_size))   # MFULL:1136 (768 -> clip_width)
+        else:
+            map_size = list(map_size if map_size is not None else (config.map_size or [192, 256, 64, 16]))   # MFULL:1099 default
+            self.prompt_mlp = MLP(map_size, hidden_size=768)                                                # MFULL:1138
         self.prompt_size, self.prompt_mlp_type = prompt_size, prompt_mlp_type
         if d == 1024:
             self.visual_map = nn.Linear(768, 1024)
@@ -295,7 +324,9 @@ class BartEncoder(nn.Module):
                                self.embed_scale, self.dropout, self.training, self.padding_idx)           # :1254-1260
             fn_mask = torch.cat((face_mask.to(torch.uint8), name_mask.to(torch.uint8)), dim=1).contiguous()   # :1262 (mask bytes only)
             face = ops.linear(ops.to_bf16(face_features), self._linear_1.weight, self.s_l1)              # :1269
-        img = self.prompt_mlp(ops.to_bf16(image_features)).reshape(B, self.prompt_size, 768)              # :1274-1276
+        img = self.prompt_mlp(ops.to_bf16(image_features))                                               # :1274
+        if self.prompt_mlp_type == "clipcap":
+            img = img.reshape(B, self.prompt_size, 768)                                                   # :1275-1276
         if self.embed_dim == 1024:
             img = ops.linear(img, self.visual_map.weight, self.s_vmap)                                   # :1277-1278
         # img_ner_mask_cross is all ones (:1280-1296) -> no key mask on the visual/name cross-attention

@@ -169,6 +169,72 @@ def mlp2(x, anchor, s1, s2, act="gelu"):
     return Mlp2Fn.apply(x, anchor, s1, s2, act, torch.is_grad_enabled())
 
 
+class MlpChainFn(Function):
+    """y = W_n act(... act(W_1 x + b_1) ...) + b_n — the token-mixing prompt MLP of `--prompt_mlp_type mlp` (MFULL:76-108):
+    any number of Linear layers with `act` between them.  The first layer's input width (the ViT's patch-token count, 196 for
+    ViT-B/16) need not be a multiple of 8: x and W_1 are repacked to 16-byte rows (zero columns contribute nothing), and the
+    weight gradient is accumulated straight into the unpadded [N, K] gradient view.  Hidden widths are multiples of 8
+    (VacnicConfig.validate).  Activation backward is fused into the dgrad epilogue of the following layer (dact_src)."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, specs, act, ge):
+        s0 = specs[0]
+        x2 = _c(x).view(-1, s0.K)
+        M = x2.shape[0]
+        need = ge and any(ctx.needs_input_grad)
+        Kp = (s0.K + 7) // 8 * 8
+        w0 = s0.w16
+        if Kp != s0.K:
+            x2 = K.pad_cols(x2, Kp)
+            w0 = K.pad_cols(w0, Kp)
+        elif s0.ldw % 8:
+            w0 = K.pad_cols(w0, Kp)
+        saved, h = [x2], x2
+        for i, sp in enumerate(specs):
+            last = i == len(specs) - 1
+            u = torch.empty((M, sp.N), device=x.device, dtype=BF16) if (need and not last) else None
+            o = torch.empty((M, sp.N), device=x.device, dtype=BF16)
+            w, ldw, kd = (w0, w0.stride(0), Kp) if i == 0 else (sp.w16, sp.ldw, sp.K)
+            K.gemm(h, w, M, sp.N, kd, bias=sp.bias, out=o, ldx=h.stride(0), ldw=ldw, act=None if last else act, preact=u)
+            if not last:
+                saved += [u, o]
+            h = o
+        ctx.specs, ctx.act, ctx.M, ctx.xshape = specs, act, M, x.shape
+        ctx.save_for_backward(*saved)
+        for sp in specs:
+            ddp.expect(need, sp.wgrad, sp.bgrad)
+        return h
+
+    @staticmethod
+    def backward(ctx, dy):
+        saved = ctx.saved_tensors
+        specs, act, M = ctx.specs, ctx.act, ctx.M
+        d = _c(dy).view(M, specs[-1].N)
+        for i in range(len(specs) - 1, -1, -1):
+            sp = specs[i]
+            inp = saved[0] if i == 0 else saved[2 * i]              # this layer's input: x, or the previous activation output
+            if i > 0:
+                u_prev = saved[2 * i - 1]
+                dprev = torch.empty((M, sp.K), device=dy.device, dtype=BF16)
+                K.gemm(d, sp.w16, M, sp.K, sp.N, out=dprev, ldx=d.stride(0), ldw=sp.ldw, w_kstrided=True, act=act, dact_src=u_prev)
+            _wgrad(d, inp, sp, M)                                   # layer 0: inp is the 16-byte-row repack; only the first K columns are written
+            if i > 0:
+                d = dprev
+        dx = None
+        if ctx.needs_input_grad[0]:
+            s0 = specs[0]
+            if s0.K % 8:
+                raise NotImplementedError("input gradient through a ragged-K first layer (the image features are frozen: TRAIN:274-276)")
+            dx = torch.empty((M, s0.K), device=dy.device, dtype=BF16)
+            K.gemm(d, s0.w16, M, s0.K, s0.N, out=dx, ldw=s0.ldw, w_kstrided=True)
+            dx = dx.view(ctx.xshape)
+        return dx, None, None, None, None
+
+
+def mlp_chain(x, anchor, specs, act="tanh"):
+    return MlpChainFn.apply(x, anchor, tuple(specs), act, torch.is_grad_enabled())
+
+
 # ---------------------------------------------------------------------------------------- attention
 class SelfAttnFn(Function):
     """kvq: [B,T,3d] fused projection output, column blocks [K | V | Q] (arena order k,v,q)."""

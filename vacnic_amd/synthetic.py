@@ -26,6 +26,14 @@ def _attn_names(prefix):
     return out
 
 
+def image_features(cfg: VacnicConfig, B, seed=3):
+    """stand-in for extract_clip_img_feat's output that feeds `image_features`: the ln_post CLS vector [B, clip_width]
+    (ClipCap prompt) or the ln_post patch tokens [B, map_size[0], 768] (--prompt_mlp_type mlp)."""
+    if cfg.prompt_mlp_type == "mlp":
+        return _normal("img_feat", (B, cfg.map_size[0], 768), 1.0, seed)
+    return _normal("img_cls", (B, cfg.clip_width), 1.0, seed)
+
+
 def mmbart_param_shapes(cfg: VacnicConfig):
     """name -> shape, reference parameter names (MFULL state_dict order is not required)."""
     d, V = cfg.d_model, cfg.vocab_size
@@ -34,8 +42,13 @@ def mmbart_param_shapes(cfg: VacnicConfig):
     s[f"{e}.embed_positions.weight"] = (cfg.max_position_embeddings + 2, d)
     s[f"{e}.layernorm_embedding.weight"] = (d,); s[f"{e}.layernorm_embedding.bias"] = (d,)
     P = cfg.prompt_size
-    s[f"{e}.prompt_mlp.model.0.weight"] = (768 * P // 2, cfg.clip_width); s[f"{e}.prompt_mlp.model.0.bias"] = (768 * P // 2,)
-    s[f"{e}.prompt_mlp.model.2.weight"] = (768 * P, 768 * P // 2); s[f"{e}.prompt_mlp.model.2.bias"] = (768 * P,)
+    if cfg.prompt_mlp_type == "mlp":               # MFULL:76-108: Linear at Sequential slots 0, 2, 4, ...
+        for i in range(len(cfg.map_size) - 1):
+            s[f"{e}.prompt_mlp.model.{2 * i}.weight"] = (cfg.map_size[i + 1], cfg.map_size[i])
+            s[f"{e}.prompt_mlp.model.{2 * i}.bias"] = (cfg.map_size[i + 1],)
+    else:
+        s[f"{e}.prompt_mlp.model.0.weight"] = (768 * P // 2, cfg.clip_width); s[f"{e}.prompt_mlp.model.0.bias"] = (768 * P // 2,)
+        s[f"{e}.prompt_mlp.model.2.weight"] = (768 * P, 768 * P // 2); s[f"{e}.prompt_mlp.model.2.bias"] = (768 * P,)
     if d == 1024:
         s[f"{e}.visual_map.weight"] = (1024, 768); s[f"{e}.visual_map.bias"] = (1024,)
     if not cfg.only_image:

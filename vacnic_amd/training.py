@@ -77,7 +77,7 @@ def build_models(cfg: VacnicConfig, vcfg: ClipVisionConfig, device="cuda", seed=
     from . import synthetic
     clip_model = CLIPVisualOnly(vcfg)
     model = BartForMultiModalGeneration(cfg, enc_fusion_layer=cfg.enc_fusion_layer, dim_common=cfg.dim_common, img_size=768,
-                                        prompt_mlp_type=cfg.prompt_mlp_type, prompt_size=cfg.prompt_size, clip_model=None,
+                                        prompt_mlp_type=cfg.prompt_mlp_type, map_size=cfg.map_size, prompt_size=cfg.prompt_size, clip_model=None,
                                         freeze_clip=True, max_ner_type_len=cfg.max_ner_type_len,
                                         max_ner_type_len_gt=cfg.max_ner_type_len_gt, only_image=cfg.only_image)
     guide = BartForConditionalGeneration(cfg)
@@ -121,19 +121,26 @@ def to_device(batch, device):
     return {k: v.to(device, non_blocking=True) for k, v in batch.items()}
 
 
+def image_feature_index(cfg):
+    """which output of extract_clip_img_feat feeds `image_features`: the ln_post CLS vector for the ClipCap prompt MLP, the
+    ln_post patch tokens for `--prompt_mlp_type mlp` (the reference trainers branch the same way at every model call)."""
+    return 1 if cfg.prompt_mlp_type == "clipcap" else 0
+
+
 def forward_losses(model, guide, batch, args: TrainArgs, ready=None, towers=None):
     """Forward of one step; returns (total, out4={total, txt, secla, colam}, model_out).  `model` may be the DDP wrapper
     (like TRAIN:274 `model.module`).  `ready`: optional event after which the batch tensors are valid in HBM; with side
     streams enabled the frozen towers then start on it instead of on the compute stream's tail (= the previous AdamW)."""
     net = model.module if isinstance(model, DistributedDataParallel) else model
     cfg = net.config
+    feat = image_feature_index(cfg)
     src, tgt = batch["article_ids"], batch["caption_ids"]
     main = torch.cuda.current_stream()
     aux, vis = streams.aux_stream(), streams.vit_stream()
     if aux is None:
         src_mask, _ = K.prep_ids(src, cfg.pad_token_id)                                      # create_src_mask_bart, TRAIN:268
         tgt_mask, tgt_in = K.prep_ids(tgt, cfg.pad_token_id, start_id=cfg.eos_token_id)     # shift_tokens_right, TRAIN:267,296
-        _, img_cls = extract_clip_img_feat(net.clip_model, batch["img_tensor"])               # TRAIN:274-276
+        img_cls = extract_clip_img_feat(net.clip_model, batch["img_tensor"])[feat]            # TRAIN:274-276
     elif towers is not None:
         # frozen towers as two hipGraph replays on their side streams (FrozenTowerGraphs)
         src_mask, tgt_mask, tgt_in, ev_prep = towers.launch(batch, ready)
@@ -158,7 +165,7 @@ def forward_losses(model, guide, batch, args: TrainArgs, ready=None, towers=None
             if guide is not None:
                 gh = guide(input_ids=src, attention_mask=src_mask, decoder_input_ids=tgt_in)["decoder_hidden_states"][-1]   # TRAIN:293-294
         with torch.cuda.stream(vis):
-            _, img_cls = extract_clip_img_feat(net.clip_model, batch["img_tensor"])
+            img_cls = extract_clip_img_feat(net.clip_model, batch["img_tensor"])[feat]
         main.wait_event(ev_prep)
         main.wait_stream(vis)
         for tns in (src_mask, tgt_mask, tgt_in, img_cls):
@@ -274,7 +281,7 @@ class FrozenTowerGraphs:
             return guide(input_ids=self.src_s, attention_mask=self.mask_s, decoder_input_ids=self.tgtin_s)["decoder_hidden_states"][-1]
 
         def vit_body():
-            return extract_clip_img_feat(net.clip_model, self.img_s)[1]
+            return extract_clip_img_feat(net.clip_model, self.img_s)[image_feature_index(cfg)]
 
         torch.cuda.synchronize()
         with torch.no_grad():
