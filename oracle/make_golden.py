@@ -69,6 +69,8 @@ def build_ref_model(mod, cfg: VacnicConfig, sd):
         kw["only_image"] = cfg.only_image
     if cfg.prompt_mlp_type == "mlp":
         kw["map_size"] = list(cfg.map_size)
+    if cfg.init_attn_weight:
+        kw["init_attn_weight"] = True
     m = mod.BartForMultiModalGeneration(bart_config(cfg), **kw)
     if cfg.clip_width != 768 and cfg.prompt_mlp_type == "clipcap":
         # documented one-line deviation (SURVEY "facts"): the 768 at MFULL:1136 is the CLIP width
@@ -101,6 +103,11 @@ def mlp_cfg():
                      map_size=[12, 32, 16, 8])
 
 
+def tied_cfg():
+    """--init_attn_weight True (MFULL:1858-1870): name self-attn + image/name cross-attn weights tied to the text self-attn."""
+    return small_cfg(encoder_layers=2, decoder_layers=1, enc_fusion_layer=[0, 1], init_attn_weight=True)
+
+
 def slices(t, n=4096):
     """deterministic strided sample of a tensor + its full-tensor checksum."""
     f = t.detach().reshape(-1).double()
@@ -111,7 +118,9 @@ def slices(t, n=4096):
 def run_full_case(name, mfull, train, BatchSoftmax, cfg, B, S, T, F, grads=True):
     torch.manual_seed(0)
     sd = synthetic.make_state_dict(synthetic.mmbart_param_shapes(cfg), seed=1)
-    gcfg = VacnicConfig(**{**cfg.__dict__, "enc_fusion_layer": [], "only_image": False})
+    if cfg.init_attn_weight:
+        synthetic.apply_init_attn_weight(sd, cfg)
+    gcfg = VacnicConfig(**{**cfg.__dict__, "enc_fusion_layer": [], "only_image": False, "init_attn_weight": False})
     sd_g = synthetic.make_state_dict(synthetic.guide_bart_param_shapes(cfg), seed=2)
     model = build_ref_model(mfull, cfg, sd)
     batch = synthetic.make_batch(cfg, B, S=S, T=T, F=F, seed=7, image_size=32)
@@ -157,6 +166,8 @@ def run_full_case(name, mfull, train, BatchSoftmax, cfg, B, S, T, F, grads=True)
     if grads:
         loss.backward()
         for pname in ("model.shared.weight", "model.encoder.layers.0.self_attn.q_proj.weight",
+                      "model.encoder.layers.1.self_attn.out_proj.weight", "model.encoder.layers.0.self_attn.k_proj.weight",
+                      "model.encoder.layers.1.cross_attn_img_ner.q_proj.bias", "model.encoder.layers.0.self_attn_img_name.v_proj.bias",
                       "model.encoder.layers.0.ner_map_up.weight", "model.encoder.layers.0._face_up.weight",
                       "model.encoder.layers.0.cross_attn_img_ner.k_proj.weight", "model.encoder.layers.1.fc1.weight",
                       "model.encoder.prompt_mlp.model.0.weight", "model.encoder.prompt_mlp.model.2.bias",
@@ -360,6 +371,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "mlp":
         run_full_case("mfull_mlp_d1024", mfull, train, BatchSoftmax, mlp_cfg(), B=2, S=40, T=10, F=2)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "tied":
+        run_full_case("mfull_tied_d768", mfull, train, BatchSoftmax, tied_cfg(), B=2, S=40, T=10, F=2)
+        return
     run_collate()
     run_helpers(train, BatchSoftmax)
     run_generate_case(mfull, train)
@@ -371,6 +385,7 @@ def main():
                             clip_width=1024), B=2, S=40, T=10, F=2)
     run_mvis_case("mvis_d768", mvis, train, small_cfg(only_image=True, enc_fusion_layer=[0, 1]), B=2, S=32, T=8)
     run_full_case("mfull_mlp_d1024", mfull, train, BatchSoftmax, mlp_cfg(), B=2, S=40, T=10, F=2)
+    run_full_case("mfull_tied_d768", mfull, train, BatchSoftmax, tied_cfg(), B=2, S=40, T=10, F=2)
 
 
 if __name__ == "__main__":

@@ -117,6 +117,16 @@ def test_ops_fail_loudly_without_gpu():
         m(input_ids=torch.zeros(1, 4, dtype=torch.long), attention_mask=torch.ones(1, 4, dtype=torch.long))
 
 
+def test_non_secla_branch_fails_like_the_reference():
+    """`--use_secla False` (TRAIN:331-345) calls the model with add_ner_ffn=False; the reference's encoder raises a mask-size
+    ValueError there (checked by running it: DESIGN.md §8) — same exception type here, before any device work."""
+    from types import SimpleNamespace
+    from vacnic_amd.training import TrainArgs, forward_losses
+    net = SimpleNamespace(config=small_cfg())
+    with pytest.raises(ValueError, match="add_ner_ffn=False"):
+        forward_losses(net, None, {}, TrainArgs(use_secla=False, no_mapping=False))
+
+
 def test_unsupported_flags_raise():
     from vacnic_amd.models.mmbart import BartAttention, BartForMultiModalGeneration
     with pytest.raises(ValueError, match="divisible"):
@@ -125,8 +135,16 @@ def test_unsupported_flags_raise():
     names = [n for n, _ in m.named_parameters() if "prompt_mlp" in n]          # MFULL:76-108: Linear at Sequential slots 0, 2, 4
     assert names == [f"model.encoder.prompt_mlp.model.{i}.{w}" for i in (0, 2, 4) for w in ("weight", "bias")]
     assert tuple(m.model.encoder.prompt_mlp.model[0].weight.shape) == (256, 196)
-    with pytest.raises(NotImplementedError):
-        BartForMultiModalGeneration(small_cfg(), enc_fusion_layer=[0], dim_common=768, init_attn_weight=True)
+    t = BartForMultiModalGeneration(small_cfg(), enc_fusion_layer=[0], dim_common=768, init_attn_weight=True)      # MFULL:1858-1870
+    l0 = t.model.encoder.layers[0]
+    assert l0.self_attn_img_name.q_proj.weight is l0.self_attn.q_proj.weight and l0.cross_attn_img_ner.out_proj.weight is l0.self_attn.out_proj.weight
+    assert l0.self_attn_img_name.q_proj.bias is not l0.self_attn.q_proj.bias
+    t.finalize("cpu")                                  # the arena places a tied weight once; all three attentions see the same views
+    assert l0.cross_attn_img_ner.s_kvq.w16.data_ptr() == l0.self_attn.s_kvq.w16.data_ptr()
+    assert l0.cross_attn_img_ner.s_kvq.wgrad.data_ptr() == l0.self_attn.s_kvq.wgrad.data_ptr()
+    assert l0.cross_attn_img_ner.s_kvq.bias.data_ptr() != l0.self_attn.s_kvq.bias.data_ptr()
+    with pytest.raises(AttributeError):               # like the reference: only_image layers have no name self-attention to tie
+        BartForMultiModalGeneration(small_cfg(only_image=True), enc_fusion_layer=[0], dim_common=768, only_image=True, init_attn_weight=True)
 
 
 def test_resize_token_embeddings_keeps_tie():

@@ -31,6 +31,8 @@ CASES = {
     "mfull_mlp_d1024": (dict(d_model=1024, encoder_layers=1, decoder_layers=1, encoder_attention_heads=16, decoder_attention_heads=16,
                              encoder_ffn_dim=2048, decoder_ffn_dim=2048, dim_common=1024, clip_width=768, prompt_mlp_type="mlp",
                              map_size=[12, 32, 16, 8]), dict(B=2, S=40, T=10, F=2)),
+    # --init_attn_weight True (MFULL:1858-1870): tied attention weights, gradients summed over the three uses
+    "mfull_tied_d768": (dict(encoder_layers=2, decoder_layers=1, enc_fusion_layer=[0, 1], init_attn_weight=True), dict(B=2, S=40, T=10, F=2)),
 }
 
 
@@ -94,6 +96,8 @@ def test_full_model_matches_oracle_and_reference_golden(case, side_streams):
     assert (am == gold["argmax"]).mean() >= 0.97, "teacher-forced argmax ids vs reference"
     # --- gradients vs the oracle's autograd on CPU (same weights)
     sd = synthetic.make_state_dict(synthetic.mmbart_param_shapes(cfg), seed=1)
+    if cfg.init_attn_weight:
+        synthetic.apply_init_attn_weight(sd, cfg)
     sd_g = synthetic.make_state_dict(synthetic.guide_bart_param_shapes(cfg), seed=2)
     for v in sd.values():
         v.requires_grad_(True)

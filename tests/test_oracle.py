@@ -32,6 +32,9 @@ CASES = {
     "mfull_mlp_d1024": (small_cfg(d_model=1024, encoder_layers=1, decoder_layers=1, encoder_attention_heads=16,
                                   decoder_attention_heads=16, encoder_ffn_dim=2048, decoder_ffn_dim=2048, dim_common=1024,
                                   clip_width=768, prompt_mlp_type="mlp", map_size=[12, 32, 16, 8]), dict(B=2, S=40, T=10, F=2)),
+    # --init_attn_weight True (MFULL:1858-1870): three attentions per encoder layer share their weight Parameters
+    "mfull_tied_d768": (small_cfg(encoder_layers=2, decoder_layers=1, enc_fusion_layer=[0, 1], init_attn_weight=True),
+                        dict(B=2, S=40, T=10, F=2)),
 }
 
 
@@ -49,6 +52,8 @@ def check(name, t, gold, rtol=2e-4, atol=2e-5):
 
 def full_case_inputs(cfg, B, S, T, F):
     sd = synthetic.make_state_dict(synthetic.mmbart_param_shapes(cfg), seed=1)
+    if cfg.init_attn_weight:
+        synthetic.apply_init_attn_weight(sd, cfg)
     sd_g = synthetic.make_state_dict(synthetic.guide_bart_param_shapes(cfg), seed=2)
     batch = synthetic.make_batch(cfg, B, S=S, T=T, F=F, seed=7, image_size=32)
     img_cls = synthetic.image_features(cfg, B)

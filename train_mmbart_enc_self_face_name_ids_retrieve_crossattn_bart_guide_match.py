@@ -95,7 +95,8 @@ def run(args, batches=None):
     if not args.no_clip_loss or not args.freeze_clip:
         raise NotImplementedError("CLIP contrastive loss / CLIP fine-tuning are out of scope (SURVEY §2 row 20): pass --no_clip_loss True --freeze_clip True")
     if not args.no_mapping and not args.use_secla and not args.only_image:
-        raise NotImplementedError("non-SECLA face-name branch (TRAIN:332-355) is out of scope (SURVEY §2 row 21): pass --use_secla True")
+        raise ValueError("--use_secla False: the reference's pooled face-name branch (TRAIN:331-345) fails inside its own encoder "
+                         "(add_ner_ffn=False -> attention-mask size ValueError); pass --use_secla True or --no_mapping True")
     local = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0"))
     torch.cuda.set_device(local)
     if world > 1:
@@ -106,6 +107,7 @@ def run(args, batches=None):
     cfg = VacnicConfig(enc_fusion_layer=list(args.enc_fusion_layer or []), dim_common=args.dim_common, prompt_size=args.prompt_size,
                        max_ner_type_len=args.max_ner_type_len, max_ner_type_len_gt=args.max_ner_type_len_gt,
                        only_image=args.only_image, clip_width=vkw["width"], prompt_mlp_type=args.prompt_mlp_type, map_size=args.map_size,
+                       init_attn_weight=args.init_attn_weight,
                        **PLM[args.plm_type]).validate()
     vcfg = ClipVisionConfig(**vkw)
     model, guide, _ = build_models(cfg, vcfg, device="cuda", seed=int(args.seed) % (2 ** 31), init="device")

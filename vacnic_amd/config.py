@@ -35,6 +35,7 @@ class VacnicConfig:
     max_ner_type_len: int = 80
     max_ner_type_len_gt: int = 20
     only_image: bool = False
+    init_attn_weight: bool = False     # MFULL:1858-1870: tie name-self-attn / image-name cross-attn weights to the text self-attn
     face_dim: int = 512
     clip_width: int = 768              # input dim of the ClipCap MLP (hard-coded 768 at MFULL:1136; 1024 for ViT-L/14)
 

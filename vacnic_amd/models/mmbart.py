@@ -196,7 +196,14 @@ class BartEncoderLayer(nn.Module):
                 hidden_states_img = self._ln(ops.mlp2(a, self.fc1.weight, self.s_up, self.s_down), r, self.img_layer_norm)
                 if not self.only_image:
                     if not add_ner_ffn:
-                        raise NotImplementedError("add_ner_ffn=False (non-SECLA contrastive branch, SURVEY §2 row 21)")
+                        # MFULL:665-666 concatenates [img ; names ; text] as keys while the mask of MFULL:1293-1296 covers
+                        # P + max_ner_type_len_gt of them: the reference's own BartAttention rejects the call (MFULL:520-524;
+                        # verified by running the reference).  Same error, same wording.
+                        Bq, Sq = hidden_states.shape[0], hidden_states.shape[1]
+                        n_kv = hidden_states_img.shape[1] + hidden_states_ner.shape[1] + Sq
+                        n_mask = hidden_states_img.shape[1] + self.max_ner_type_len_gt
+                        raise ValueError(f"Attention mask should be of size {(Bq, 1, Sq, n_kv)}, but is "
+                                         f"torch.Size([{Bq}, 1, {Sq}, {n_mask}])")
                     # face FFN (:658-664)
                     a, r = ops.fork(hidden_states_face)
                     hidden_states_face = self._ln(ops.mlp2(a, self.fc1.weight, self.s_fup, self.s_fdown), r, self.face_layer_norm)
@@ -407,6 +414,18 @@ class BartModel(nn.Module):
                 "hidden_states_img": encoder_outputs["hidden_states_img"]}
 
 
+def init_attn_weight_encoder(encoder):
+    """MFULL:1858-1870 (`--init_attn_weight True`): in every encoder layer the q/k/v/out projection WEIGHTS (not biases) of the
+    name self-attention and of the image/name cross-attention become the text self-attention's Parameter objects — a true tie
+    for the whole run, so each weight's gradient is the sum over its three uses.  In the arena the tied attentions read the
+    same bf16 shadow and accumulate into the same gradient view (their weight-gradient GEMMs are serialized on one stream).
+    Like the reference, a layer without `self_attn_img_name` (only_image) raises AttributeError."""
+    for layer in encoder.layers:
+        for tied in (layer.self_attn_img_name, layer.cross_attn_img_ner):
+            for proj in ("q_proj", "k_proj", "v_proj", "out_proj"):
+                getattr(tied, proj).weight = getattr(layer.self_attn, proj).weight
+
+
 class BartForMultiModalGeneration(nn.Module):
     """MFULL:1877-2074 (MVIS:1731-1914 when only_image=True).  forward() returns the dict the trainer indexes
     (`logits`, `decoder_hidden_states`, `hidden_states_face`, ...; TRAIN:281-294,326).
@@ -431,8 +450,8 @@ class BartForMultiModalGeneration(nn.Module):
         if freeze_clip and clip_model is not None:
             for p in clip_model.parameters():
                 p.requires_grad = False
-        if init_attn_weight:
-            raise NotImplementedError("init_attn_weight=True (MFULL:1858-1870) aliases weights across attentions; shipped scripts use False")
+        if init_attn_weight or config.init_attn_weight:
+            init_attn_weight_encoder(self.model.encoder)
         self._init_weights()
         self.arena = None
 

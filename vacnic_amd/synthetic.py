@@ -26,6 +26,16 @@ def _attn_names(prefix):
     return out
 
 
+def apply_init_attn_weight(sd, cfg: VacnicConfig):
+    """name-keyed view of `--init_attn_weight True` (MFULL:1858-1870): the tied attentions' weight entries become the SAME tensor
+    objects as the text self-attention's (so autograd on the dict accumulates the three uses into one gradient)."""
+    for i in range(cfg.encoder_layers):
+        for tied in ("self_attn_img_name", "cross_attn_img_ner"):
+            for proj in ("q_proj", "k_proj", "v_proj", "out_proj"):
+                sd[f"model.encoder.layers.{i}.{tied}.{proj}.weight"] = sd[f"model.encoder.layers.{i}.self_attn.{proj}.weight"]
+    return sd
+
+
 def image_features(cfg: VacnicConfig, B, seed=3):
     """stand-in for extract_clip_img_feat's output that feeds `image_features`: the ln_post CLS vector [B, clip_width]
     (ClipCap prompt) or the ln_post patch tokens [B, map_size[0], 768] (--prompt_mlp_type mlp)."""

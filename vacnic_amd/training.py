@@ -79,7 +79,8 @@ def build_models(cfg: VacnicConfig, vcfg: ClipVisionConfig, device="cuda", seed=
     model = BartForMultiModalGeneration(cfg, enc_fusion_layer=cfg.enc_fusion_layer, dim_common=cfg.dim_common, img_size=768,
                                         prompt_mlp_type=cfg.prompt_mlp_type, map_size=cfg.map_size, prompt_size=cfg.prompt_size, clip_model=None,
                                         freeze_clip=True, max_ner_type_len=cfg.max_ner_type_len,
-                                        max_ner_type_len_gt=cfg.max_ner_type_len_gt, only_image=cfg.only_image)
+                                        max_ner_type_len_gt=cfg.max_ner_type_len_gt, only_image=cfg.only_image,
+                                        init_attn_weight=cfg.init_attn_weight)
     guide = BartForConditionalGeneration(cfg)
     if init == "synthetic" or state_dicts is not None:
         sds = state_dicts or (synthetic.make_state_dict(synthetic.mmbart_param_shapes(cfg), seed=seed + 1),
@@ -134,6 +135,11 @@ def forward_losses(model, guide, batch, args: TrainArgs, ready=None, towers=None
     net = model.module if isinstance(model, DistributedDataParallel) else model
     cfg = net.config
     feat = image_feature_index(cfg)
+    if not args.no_mapping and not args.use_secla and not cfg.only_image:
+        # TRAIN:331-345 (`--use_secla False`): re-runs the model with add_ner_ffn=False, which the reference's encoder rejects
+        # with a mask-shape ValueError (see BartEncoderLayer) — there is no working behaviour to reproduce
+        raise ValueError("--use_secla False with --no_mapping False: the reference's pooled face-name branch (TRAIN:331-345) "
+                         "fails inside its own encoder (add_ner_ffn=False, attention-mask size); use --use_secla True or --no_mapping True")
     src, tgt = batch["article_ids"], batch["caption_ids"]
     main = torch.cuda.current_stream()
     aux, vis = streams.aux_stream(), streams.vit_stream()
