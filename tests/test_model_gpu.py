@@ -509,6 +509,26 @@ def test_trainer_entry_point_runs_and_resumes(tmp_path):
     assert [r["step"] for r in recs3] == [1, 2, 3] and all(np.isfinite(r["loss"]) for r in recs3)
 
 
+def test_image_only_trainer_entry_point(tmp_path):
+    """the reference's second trainer file (run_onlyvis_train.sh): image-only model, text loss only; here also with the
+    token-mixing prompt MLP over ViT-B/32's 49 patch tokens, tied encoder attentions off, gradient clipping on."""
+    import json
+    import subprocess
+    import sys
+    script = os.path.join(ROOT, "run_train_mmbart_enc_self_onlyvis_retrieve_crossattn.py")
+    cmd = [sys.executable, script, "--plm_type", "facebook/bart-base", "--clip_type", "ViT-B/32", "--enc_fusion_layer", "0", "1", "2",
+           "--dim_common", "1024", "--train_batch_size", "2", "--article_max_length", "64", "--steps_per_epoch", "3", "--log_every", "1",
+           "--only_image", "True", "--no_mapping", "True", "--use_secla", "False", "--no_clip_norm", "False", "--clip_norm", "0.1",
+           "--prompt_mlp_type", "mlp", "--map_size", "49", "64", "16", "--do_retrieval", "--num_epoch", "1", "--out_dir", str(tmp_path),
+           "--experiment_name", "v"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    recs = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert [x["step"] for x in recs] == [1, 2, 3] and all(np.isfinite(x["loss"]) for x in recs)
+    assert all(abs(x["loss"] - x["text loss"]) < 1e-6 and x["face name loss"] == 0 and x["margin loss"] == 0 for x in recs), recs
+    assert os.path.exists(os.path.join(str(tmp_path), "vlast.pt"))
+
+
 def test_whole_step_hipgraph_replays_like_eager():
     """opt-in `bench.py --graph` path: the full step (all side streams, LR / dropout counters in device memory) captured once;
     replays must train like eager steps on the same batches (dropout off so the two runs are comparable)."""
