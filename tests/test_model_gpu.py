@@ -487,12 +487,23 @@ def test_trainer_entry_point_runs_and_resumes(tmp_path):
               "--use_secla", "True", "--margin", "1.0", "--alpha", "0.5", "--no_clip_norm", "True", "--out_dir", str(tmp_path),
               "--experiment_name", "t"]
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
-    r1 = subprocess.run(common + ["--num_epoch", "1"], capture_output=True, text=True, timeout=600, env=env)
+    r1 = subprocess.run(common + ["--num_epoch", "1", "--val_steps", "2", "--val_batch_size", "2", "--test_steps", "2", "--beam_size", "2",
+                                  "--max_length", "8"], capture_output=True, text=True, timeout=600, env=env)
     assert r1.returncode == 0, r1.stderr[-2000:]
-    recs1 = [json.loads(l) for l in r1.stdout.splitlines() if l.startswith("{")]
+    all1 = [json.loads(l) for l in r1.stdout.splitlines() if l.startswith("{")]
+    recs1 = [r for r in all1 if "step" in r]
     assert [r["step"] for r in recs1] == [1, 2, 3] and all(np.isfinite(r["loss"]) for r in recs1)
     ck = os.path.join(str(tmp_path), "tlast.pt")
     assert os.path.exists(ck)
+    # eval_epoch / test generation of the reference trainer (TRAIN:391-447,455-470,480-530): validation loss, best checkpoint + its
+    # teacher-forced outputs, generated captions for the test batches
+    val = [r for r in all1 if "validation loss" in r]
+    assert len(val) == 1 and np.isfinite(val[0]["validation loss"]) and 5.0 < val[0]["validation loss"] < 20.0
+    assert os.path.exists(os.path.join(str(tmp_path), "t.pt"))
+    vj = json.load(open(os.path.join(str(tmp_path), "tv.json")))
+    assert len(vj) == 2 and len(vj["0"]["logit_output"]) == 2 and len(vj["0"]["logit_output"][0]) == len(vj["0"]["gt_cap"][0])
+    tj = json.load(open(os.path.join(str(tmp_path), "t.json")))
+    assert len(tj) == 2 and tj["0"]["gen"][0][0] == 2 and 2 <= len(tj["0"]["gen"][0]) <= 8
     r2 = subprocess.run(common + ["--num_epoch", "2", "--resume", ck], capture_output=True, text=True, timeout=600, env=env)
     assert r2.returncode == 0, r2.stderr[-2000:]
     recs2 = [json.loads(l) for l in r2.stdout.splitlines() if l.startswith("{")]

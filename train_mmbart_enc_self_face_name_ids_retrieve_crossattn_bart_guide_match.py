@@ -74,6 +74,8 @@ parser.add_argument("--alpha", type=float, default=0.5)
 # additions for the synthetic driver
 parser.add_argument("--steps_per_epoch", type=int, default=20)
 parser.add_argument("--log_every", type=int, default=5)
+parser.add_argument("--val_steps", type=int, default=0, help="synthetic validation batches per epoch (eval_epoch, TRAIN:391-447); 0 = skip")
+parser.add_argument("--test_steps", type=int, default=0, help="synthetic test batches generated after training (TRAIN:480-530); 0 = skip")
 parser.add_argument("--resume", type=str, default="", help="checkpoint written by a previous run (<out_dir>/<experiment_name>last.pt): "
                     "weights, AdamW moments, LR-schedule position and dropout RNG are restored and the step count continues")
 
@@ -90,7 +92,7 @@ def run(args, batches=None):
     from vacnic_amd import ops, streams, synthetic
     from vacnic_amd.config import ClipVisionConfig, VacnicConfig
     from vacnic_amd.ddp import DistributedDataParallel
-    from vacnic_amd.training import FusedAdamW, TrainArgs, build_models, to_device, train_step
+    from vacnic_amd.training import FusedAdamW, TrainArgs, build_models, eval_epoch, gen_caption_from_loader_bart, to_device, train_step
 
     if not args.no_clip_loss or not args.freeze_clip:
         raise NotImplementedError("CLIP contrastive loss / CLIP fine-tuning are out of scope (SURVEY §2 row 20): pass --no_clip_loss True --freeze_clip True")
@@ -120,6 +122,7 @@ def run(args, batches=None):
     opt = FusedAdamW(model.arena, lr=args.lr_bart, weight_decay=args.weight_decay, num_warmup_steps=args.warmup_rate * total_steps,
                      num_training_steps=total_steps, world_size=world)
     step, t0, hist = 0, time.time(), []
+    min_val_loss = 999.0                      # TRAIN:452
     start_step = 0
     if args.resume:
         from vacnic_amd import checkpoint
@@ -154,6 +157,29 @@ def run(args, batches=None):
                        "samples_per_s": round((step - start_step) * args.train_batch_size * world / (time.time() - t0), 2)}
                 hist.append(rec)
                 print(json.dumps(rec), flush=True)
+        if args.val_steps > 0 and rank == 0:
+            # TRAIN:455-470: validation pass per epoch; the best model and its teacher-forced outputs are kept
+            vb = (synthetic.make_batch(cfg, args.val_batch_size, S=args.article_max_length, T=min(64, args.caption_max_length),
+                                       seed=(int(args.seed) + 7919) % 65536, rank=0, step=i) for i in range(args.val_steps))
+            val_loss, vdict = eval_epoch(net, vb)
+            print(json.dumps({"epoch": epoch, "validation loss": val_loss}), flush=True)
+            if val_loss < min_val_loss and args.out_dir:
+                min_val_loss = val_loss
+                os.makedirs(args.out_dir, exist_ok=True)
+                from vacnic_amd import checkpoint
+                checkpoint.save_checkpoint(os.path.join(args.out_dir, args.experiment_name + ".pt"), net, opt, step=step)
+                with open(os.path.join(args.out_dir, args.experiment_name + "v.json"), "w") as f:
+                    json.dump(vdict, f)
+    if args.test_steps > 0 and rank == 0:
+        # TRAIN:480-530,845-860: beam-search captions for the test split, written next to the checkpoints
+        tb = (synthetic.make_batch(cfg, args.test_batch_size, S=args.article_max_length, T=min(64, args.caption_max_length),
+                                   seed=(int(args.seed) + 104729) % 65536, rank=0, step=i) for i in range(args.test_steps))
+        tdict = gen_caption_from_loader_bart(net, tb, args.beam_size, args.max_length)
+        if args.out_dir:
+            os.makedirs(args.out_dir, exist_ok=True)
+            with open(os.path.join(args.out_dir, args.experiment_name + ".json"), "w") as f:
+                json.dump(tdict, f)
+        print(json.dumps({"test captions": len(tdict), "first": tdict[0]["gen"][0][:12] if tdict else []}), flush=True)
     torch.cuda.synchronize()
     if rank == 0 and args.out_dir:
         os.makedirs(args.out_dir, exist_ok=True)

@@ -225,6 +225,65 @@ def train_step(model, guide, optimizer, batch, args: TrainArgs, ready=None, towe
     return out4
 
 
+def _model_inputs(net, batch):
+    """masks + frozen-tower features for one batch, as every reference loop builds them (TRAIN:267-276,408-421,491-504)."""
+    cfg = net.config
+    src = batch["article_ids"]
+    src_mask, _ = K.prep_ids(src, cfg.pad_token_id)
+    feats = extract_clip_img_feat(net.clip_model, batch["img_tensor"])[image_feature_index(cfg)]
+    kw = {}
+    if not cfg.only_image:
+        names_mask, _ = K.prep_ids(batch["names_art_ids"], cfg.pad_token_id)
+        kw = dict(face_features=batch["face_emb"], face_mask=K.face_mask(batch["face_emb"]), name_ids=batch["names_art_ids"],
+                  name_mask=names_mask)
+    return src, src_mask, feats, kw
+
+
+@torch.no_grad()
+def eval_epoch(model, batches, device="cuda"):
+    """TRAIN:391-447 / TRAINV:203-250: teacher-forced validation pass in eval mode.  Returns (mean of the per-batch text
+    cross-entropy, out_dict) with out_dict[step] = {"logit_output": argmax token ids per sample, "gt_cap": target ids} — the
+    reference stores the same two things as decoded strings (tokenizers are outside SURVEY §8).  One host sync per batch
+    (the `.item()` of TRAIN:441), like the reference."""
+    net = model.module if isinstance(model, DistributedDataParallel) else model
+    cfg = net.config
+    was_training = net.training
+    net.eval()
+    val_loss, n, out_dict = 0.0, 0, {}
+    for step, batch in enumerate(batches):
+        batch = to_device(batch, device)
+        src, src_mask, feats, kw = _model_inputs(net, batch)
+        tgt = batch["caption_ids"]
+        _, tgt_in = K.prep_ids(tgt, cfg.pad_token_id, start_id=cfg.eos_token_id)
+        out = net(input_ids=src, attention_mask=src_mask, decoder_input_ids=tgt_in, image_features=feats, labels=tgt,
+                  output_logits=True, add_ner_ffn=True, **kw)
+        lg = out["logits"]
+        ids = K.argmax_rows(lg.view(-1, lg.shape[-1]), net.V).view(tgt.shape)
+        out_dict[step] = {"logit_output": ids.tolist(), "gt_cap": tgt.tolist()}
+        val_loss += float(out["loss"].item())
+        n += 1
+    net.train(was_training)
+    return val_loss / max(n, 1), out_dict
+
+
+@torch.no_grad()
+def gen_caption_from_loader_bart(model, batches, beam_size, max_length, device="cuda"):
+    """TRAIN:480-530 (the generation half; BLEU/ROUGE/CIDEr/METEOR scoring and detokenisation are outside SURVEY §8):
+    out_dict[step] = {"gt": target ids, "gen": generated ids} with `model.generate(num_beams=beam_size, max_length=max_length)`."""
+    net = model.module if isinstance(model, DistributedDataParallel) else model
+    was_training = net.training
+    net.eval()
+    out_dict = {}
+    for step, batch in enumerate(batches):
+        batch = to_device(batch, device)
+        src, src_mask, feats, kw = _model_inputs(net, batch)
+        gen = net.generate(input_ids=src, attention_mask=src_mask, num_beams=beam_size, max_length=max_length, image_features=feats,
+                           add_ner_ffn=True, **kw)
+        out_dict[step] = {"gt": batch["caption_ids"].tolist(), "gen": gen.tolist()}
+    net.train(was_training)
+    return out_dict
+
+
 class GraphedTrainStep:
     """The whole training step (all streams: compute, guide, weight gradients) captured once into a hipGraph and
     replayed per batch — "HIP graphs instead of a tracing compiler".  A step is ~2400 kernel launches that eager Python
