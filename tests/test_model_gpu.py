@@ -253,6 +253,29 @@ def test_train_and_generate_with_token_mixing_prompt_mlp():
     assert seq.shape[0] == 4 and seq.shape[1] <= 8 and (seq[:, 0] == 2).all()
 
 
+def test_device_init_is_reproducible_across_instances():
+    """build_models(init="device", seed) must give the same networks in every process — including derived weight copies (the ViT's
+    zero-padded patch-embedding matrix is repacked whenever the bf16 shadow is refreshed) and without the guide (inference)."""
+    from vacnic_amd import synthetic
+    from vacnic_amd.config import ClipVisionConfig
+    from vacnic_amd.models.clip_vit import extract_clip_img_feat
+    from vacnic_amd.training import build_models
+    cfg = small_cfg(encoder_layers=1, decoder_layers=1)
+    vcfg = ClipVisionConfig(width=768, layers=1, patch_size=16, image_size=32, output_dim=64)
+    torch.manual_seed(1)
+    m1, g1, c1 = build_models(cfg, vcfg, seed=11, init="device")
+    torch.manual_seed(2)                                    # the constructors' default-RNG draws differ; the seeded draw must win
+    m2, g2, c2 = build_models(cfg, vcfg, seed=11, init="device", with_guide=False)
+    assert g2 is None
+    assert torch.equal(m1.arena.flat16, m2.arena.flat16) and torch.equal(c1.visual.arena.flat16, c2.visual.arena.flat16)
+    assert torch.equal(c1.visual.s_patch.w16, c2.visual.s_patch.w16)
+    K_real = 3 * 16 * 16
+    assert torch.equal(c1.visual.s_patch.w16[:, :K_real], c1.visual.conv1.weight.w16.reshape(768, K_real))
+    img = synthetic.make_batch(cfg, 2, S=16, T=8, F=2, seed=3, image_size=32)["img_tensor"].cuda()
+    f1, f2 = extract_clip_img_feat(c1, img), extract_clip_img_feat(c2, img)
+    assert torch.equal(f1[0], f2[0]) and torch.equal(f1[1], f2[1])
+
+
 def test_train_step_with_gradient_clipping():
     """--no_clip_norm False --clip_norm 0.1 (TRAIN:365-366): the step's total gradient norm and the clipped AdamW update
     against torch.nn.utils.clip_grad_norm_ + the oracle's AdamW on the same gradient."""
@@ -504,6 +527,16 @@ def test_trainer_entry_point_runs_and_resumes(tmp_path):
     assert len(vj) == 2 and len(vj["0"]["logit_output"]) == 2 and len(vj["0"]["logit_output"][0]) == len(vj["0"]["gt_cap"][0])
     tj = json.load(open(os.path.join(str(tmp_path), "t.json")))
     assert len(tj) == 2 and tj["0"]["gen"][0][0] == 2 and 2 <= len(tj["0"]["gen"][0]) <= 8
+    # the stand-alone generator (utils/test_mmbart_clip_ddp.py, DDPINF): rebuilds the model from the checkpoint alone (geometry in
+    # its meta, CLIP tower from --seed) and must reproduce the captions the trainer generated from the in-memory model
+    inf = subprocess.run([sys.executable, os.path.join(ROOT, "utils", "test_mmbart_clip_ddp.py"), "--model_dir", str(tmp_path), "--model_name",
+                          "tlast", "--beam_size", "2", "--max_length", "8", "--length_penalty", "1.0", "--test_batch_size", "1", "--test_steps", "2",
+                          "--article_max_length", "64"], capture_output=True, text=True, timeout=600, env=env)
+    assert inf.returncode == 0, inf.stderr[-2000:]
+    info = json.loads([l for l in inf.stdout.splitlines() if l.startswith("{")][-1])
+    assert info["captions"] == 2 and info["n_gpus"] == 1
+    ij = json.load(open(os.path.join(str(tmp_path), "tlast" + info["tag"] + ".json")))
+    assert {k: v["gen"] for k, v in ij.items()} == {k: v["gen"] for k, v in tj.items()}, (ij, tj)
     r2 = subprocess.run(common + ["--num_epoch", "2", "--resume", ck], capture_output=True, text=True, timeout=600, env=env)
     assert r2.returncode == 0, r2.stderr[-2000:]
     recs2 = [json.loads(l) for l in r2.stdout.splitlines() if l.startswith("{")]

@@ -167,7 +167,7 @@ def run(args, batches=None):
                 min_val_loss = val_loss
                 os.makedirs(args.out_dir, exist_ok=True)
                 from vacnic_amd import checkpoint
-                checkpoint.save_checkpoint(os.path.join(args.out_dir, args.experiment_name + ".pt"), net, opt, step=step)
+                checkpoint.save_checkpoint(os.path.join(args.out_dir, args.experiment_name + ".pt"), net, opt, step=step, config=dict(cfg.__dict__), vision=dict(vcfg.__dict__))
                 with open(os.path.join(args.out_dir, args.experiment_name + "v.json"), "w") as f:
                     json.dump(vdict, f)
     if args.test_steps > 0 and rank == 0:
@@ -184,7 +184,7 @@ def run(args, batches=None):
     if rank == 0 and args.out_dir:
         os.makedirs(args.out_dir, exist_ok=True)
         from vacnic_amd import checkpoint          # MFULL-named state_dict + optimizer/schedule/RNG (TRAIN:472 pickles the module object)
-        checkpoint.save_checkpoint(os.path.join(args.out_dir, args.experiment_name + "last.pt"), net, opt, step=step)
+        checkpoint.save_checkpoint(os.path.join(args.out_dir, args.experiment_name + "last.pt"), net, opt, step=step, config=dict(cfg.__dict__), vision=dict(vcfg.__dict__))
     if world > 1:
         dist.destroy_process_group()
     return hist

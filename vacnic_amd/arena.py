@@ -54,6 +54,7 @@ class ParamArena:
         self.flat16 = torch.zeros(self.n, device=self.device, dtype=torch.bfloat16)
         self.grad = torch.zeros(self.n, device=self.device, dtype=torch.float32) if trainable else None
         self.exp_avg = self.exp_avg_sq = None
+        self.refresh_hooks = []            # callables re-deriving packed copies of weights after refresh_shadow()
         self.params = []
         for p in model.parameters():
             if id(p) in {id(q) for q in self.params}:
@@ -104,6 +105,8 @@ class ParamArena:
         else:
             # host-side arenas exist only for layout / reducer tests (gloo); no compute op accepts CPU tensors
             self.flat16.copy_(self.flat32)
+        for hook in self.refresh_hooks:
+            hook()
 
     def init_optimizer_state(self):
         self.exp_avg = torch.zeros(self.n, device=self.device, dtype=torch.float32)

@@ -68,8 +68,14 @@ class VisionTransformer(nn.Module):
         self.Kp = (K_real + 31) // 32 * 32
         # conv1 weight [w,3,p,p] -> GEMM weight [w, Kp] bf16, zero padded (frozen: built once)
         wmat = torch.zeros((v.width, self.Kp), device=device, dtype=torch.bfloat16)
-        wmat[:, :K_real] = self.conv1.weight.w16.reshape(v.width, K_real)
         self.s_patch = LinearSpec(wmat)
+
+        def repack():           # in place: tower hipGraphs captured earlier keep pointing at the same buffer
+            wmat[:, :K_real] = self.conv1.weight.w16.reshape(v.width, K_real)
+        repack()
+        # the repack is a derived copy of conv1.weight: redo it whenever the arena's bf16 shadow is refreshed (weights drawn or
+        # loaded after finalize) — without this the tower kept the constructor's random patch embedding
+        self.arena.refresh_hooks.append(repack)
         self.blocks = []
         for blk in self.transformer.resblocks:
             self.blocks.append(dict(

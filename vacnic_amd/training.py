@@ -70,7 +70,7 @@ class FusedAdamW:
         return {"exp_avg": self.arena.exp_avg, "exp_avg_sq": self.arena.exp_avg_sq, "hyper": self.hyper}
 
 
-def build_models(cfg: VacnicConfig, vcfg: ClipVisionConfig, device="cuda", seed=0, init="device", state_dicts=None):
+def build_models(cfg: VacnicConfig, vcfg: ClipVisionConfig, device="cuda", seed=0, init="device", state_dicts=None, with_guide=True):
     """Random-init (or state-dict) construction of the three networks of the step, finalized in HBM arenas.
     init='device': N(0, 0.02) drawn on the GPU (fast, for benchmarks); init='synthetic': name-keyed numpy
     weights identical to the oracle's (parity tests)."""
@@ -81,18 +81,24 @@ def build_models(cfg: VacnicConfig, vcfg: ClipVisionConfig, device="cuda", seed=
                                         freeze_clip=True, max_ner_type_len=cfg.max_ner_type_len,
                                         max_ner_type_len_gt=cfg.max_ner_type_len_gt, only_image=cfg.only_image,
                                         init_attn_weight=cfg.init_attn_weight)
-    guide = BartForConditionalGeneration(cfg)
+    guide = BartForConditionalGeneration(cfg) if with_guide else None      # with_guide=False: inference (no CoLaM teacher)
     if init == "synthetic" or state_dicts is not None:
         sds = state_dicts or (synthetic.make_state_dict(synthetic.mmbart_param_shapes(cfg), seed=seed + 1),
                               synthetic.make_state_dict(synthetic.guide_bart_param_shapes(cfg), seed=seed + 2),
                               synthetic.make_state_dict(synthetic.clip_visual_param_shapes(vcfg), seed=seed + 4, std=0.05))
-        load_named(model, sds[0]); load_named(guide, sds[1]); load_named(clip_model.visual, sds[2])
+        load_named(model, sds[0]); load_named(clip_model.visual, sds[2])
+        if guide is not None:
+            load_named(guide, sds[1])
     model.finalize(device)
-    guide.finalize(device)
+    if guide is not None:
+        guide.finalize(device)
     clip_model.finalize(device)
     if init == "device" and state_dicts is None:
-        g = torch.Generator(device=device).manual_seed(seed)
-        for m, std in ((model, cfg.init_std), (guide, cfg.init_std), (clip_model.visual, 0.02)):
+        # one generator per network: the frozen CLIP tower a trainer drew from `seed` is reproducible without building the guide
+        for k, (m, std) in enumerate(((model, cfg.init_std), (guide, cfg.init_std), (clip_model.visual, 0.02))):
+            if m is None:
+                continue
+            g = torch.Generator(device=device).manual_seed(seed + 7919 * k)
             for name, p in m.named_parameters():
                 if p.dim() >= 2 or "embedding" in name:
                     p.data.normal_(0.0, std, generator=g)
@@ -267,9 +273,10 @@ def eval_epoch(model, batches, device="cuda"):
 
 
 @torch.no_grad()
-def gen_caption_from_loader_bart(model, batches, beam_size, max_length, device="cuda"):
+def gen_caption_from_loader_bart(model, batches, beam_size, max_length, device="cuda", length_penalty=1.0):
     """TRAIN:480-530 (the generation half; BLEU/ROUGE/CIDEr/METEOR scoring and detokenisation are outside SURVEY §8):
-    out_dict[step] = {"gt": target ids, "gen": generated ids} with `model.generate(num_beams=beam_size, max_length=max_length)`."""
+    out_dict[step] = {"gt": target ids, "gen": generated ids} with `model.generate(num_beams=beam_size, max_length=max_length)`;
+    `length_penalty` is the extra knob of the stand-alone generator (DDPINF:38,867)."""
     net = model.module if isinstance(model, DistributedDataParallel) else model
     was_training = net.training
     net.eval()
@@ -278,7 +285,7 @@ def gen_caption_from_loader_bart(model, batches, beam_size, max_length, device="
         batch = to_device(batch, device)
         src, src_mask, feats, kw = _model_inputs(net, batch)
         gen = net.generate(input_ids=src, attention_mask=src_mask, num_beams=beam_size, max_length=max_length, image_features=feats,
-                           add_ner_ffn=True, **kw)
+                           length_penalty=length_penalty, add_ner_ffn=True, **kw)
         out_dict[step] = {"gt": batch["caption_ids"].tolist(), "gen": gen.tolist()}
     net.train(was_training)
     return out_dict
