@@ -551,6 +551,16 @@ def test_trainer_entry_point_runs_and_resumes(tmp_path):
     assert r3.returncode == 0, r3.stderr[-2000:]
     recs3 = [json.loads(l) for l in r3.stdout.splitlines() if l.startswith("{")]
     assert [r["step"] for r in recs3] == [1, 2, 3] and all(np.isfinite(r["loss"]) for r in recs3)
+    # ... and the stand-alone generator over a packed test shard, 5 samples in batches of 2 (last batch ragged)
+    with data.ShardWriter(os.path.join(str(tmp_path), "test.vshard")) as w:
+        for s_ in synthetic.make_samples(5, seed=4, max_article=64, image_size=224):
+            w.add(s_)
+    r4 = subprocess.run([sys.executable, os.path.join(ROOT, "utils", "test_mmbart_clip_ddp.py"), "--model_dir", str(tmp_path), "--model_name",
+                         "ulast", "--beam_size", "3", "--max_length", "6", "--length_penalty", "2.0", "--test_batch_size", "2", "--data_type", "shard",
+                         "--data_dir", str(tmp_path)], capture_output=True, text=True, timeout=600, env=env)
+    assert r4.returncode == 0, r4.stderr[-2000:]
+    info4 = json.loads([l for l in r4.stdout.splitlines() if l.startswith("{")][-1])
+    assert info4["captions"] == 5 and info4["batches"] == 3
 
 
 def test_image_only_trainer_entry_point(tmp_path):

@@ -86,7 +86,13 @@ def run(args):
         from vacnic_amd import data
         loader = data.PrefetchLoader(data.ShardReader(os.path.join(args.data_dir, "test.vshard")), args.test_batch_size, rank=rank, world=world,
                                      shuffle=False, drop_last=False, flip=False)
-        batches = (b for b, _ in loader)
+
+        def staged():
+            for b, ev in loader:                      # (device batch, copy-stream event): decode only after the batch has landed
+                if ev is not None:
+                    torch.cuda.current_stream().wait_event(ev)
+                yield b
+        batches = staged()
         steps = None
     else:
         batches = (synthetic.make_batch(cfg, args.test_batch_size, S=args.article_max_length, T=min(64, args.caption_max_length), seed=(int(args.seed) + 104729) % 65536,
