@@ -499,6 +499,49 @@ def test_cfg4_long_article_1024_tokens_step_and_oracle():
     assert hist[-1][1] < hist[0][1], hist
 
 
+def test_cfg2_full_size_step_properties():
+    """BASELINE configs[1] at FULL size (BART-large + CLIP ViT-L/14, batch 32, 512-token articles, 64-token captions) — too big for
+    the CPU oracle, so size-independent properties of the step:
+      (a) the text loss of a freshly initialised model is ln(V) within 5 %;
+      (b) every loss term is invariant under a permutation of the samples (CE and CoLaM are means over samples/tokens, SECLA sums
+          over sample pairs), and per-sample outputs move with their sample — bit-exact where no cross-sample reduction exists;
+      (c) the global gradient norm (vacnic_grad_clip_coef) is the same for the permuted batch, to fp32 reduction-order noise;
+      (d) the same step twice on the same batch (dropout off) reproduces the losses to atomics-order noise."""
+    from vacnic_amd import kernels as K, streams, synthetic
+    from vacnic_amd.config import bart_large_vit_l14
+    from vacnic_amd.training import TrainArgs, build_models, forward_losses, to_device
+    cfg, vcfg = bart_large_vit_l14(dropout=0.0)
+    model, guide, _ = build_models(cfg, vcfg, init="device", seed=5)
+    model.train()
+    args = TrainArgs()
+    streams.enable(True)
+    batch = to_device(synthetic.make_batch(cfg, 32, S=512, T=64, seed=77), "cuda")
+    perm = torch.randperm(32, generator=torch.Generator().manual_seed(3)).cuda()
+    pbatch = {k: v[perm].contiguous() for k, v in batch.items()}
+
+    def step(b):
+        total, out4, out = forward_losses(model, guide, b, args)
+        face = out["hidden_states_face"].detach().clone()
+        total.backward()
+        streams.join_all()
+        norm = K.grad_clip_coef(model.arena.grad, model.arena.n, 1.0)[1].item()
+        model.arena.grad.zero_()
+        return out4.tolist(), face, norm
+
+    l1, f1, n1 = step(batch)
+    l2, f2, n2 = step(pbatch)
+    l3, f3, n3 = step(batch)
+    streams.enable(False)
+    assert np.isfinite(l1).all() and abs(l1[1] - np.log(cfg.vocab_size)) < 0.05 * np.log(cfg.vocab_size), l1          # (a)
+    for a, b, what in zip(l1, l2, ("total", "txt", "secla", "colam")):                                                   # (b)
+        assert abs(a - b) <= 2e-3 * abs(a) + 1e-4, (what, a, b)
+    assert torch.equal(f2, f1[perm]), "per-sample face states must follow their sample exactly"
+    assert abs(n1 - n2) <= 2e-3 * n1, (n1, n2)                                                                           # (c)
+    for a, b in zip(l1, l3):                                                                                             # (d)
+        assert abs(a - b) <= 1e-4 * abs(a) + 1e-5, (l1, l3)
+    assert torch.equal(f1, f3) and abs(n1 - n3) <= 1e-4 * n1
+
+
 def test_trainer_entry_point_runs_and_resumes(tmp_path):
     """the reference-named trainer script, its flag surface and --resume (child processes, like torchrun would start it)."""
     import json
