@@ -3,6 +3,7 @@
 // get_linear_schedule_with_warmup (TRAIN:99-107).  lr/step live in device memory so the whole
 // step is hipGraph-capturable.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -19,6 +20,7 @@ __global__ void lr_step_kernel(float* hyper, float base_lr, float warmup, float 
   }
 }
 
+template <int UNR>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, bf16_t* __restrict__ pb,
                                                     const float* __restrict__ hyper, long n4, float b1, float b2,
@@ -28,20 +30,36 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
   if (clip) gscale *= clip[0];                  // clip_grad_norm_'s coefficient, computed on device by grad_clip_coef
   const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
   const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2), decay = 1.f - lr * wd;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-    f32x4 pv = ((f32x4*)p)[i], gv = ((f32x4*)g)[i], mv = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
+  const long stride = (long)gridDim.x * blockDim.x;
+  // Launch shape (profiles/r1_adamw_microbench.txt): ALONE on the GPU this pass is fastest with one 4-wave workgroup per CU
+  // (256 workgroups: 6.2 TB/s; 2048: 4.6; 65536: 5.0 on a 440M-parameter arena) — but in the training step it shares the GPU
+  // with the next step's frozen-tower graphs, where a 256-workgroup launch loses its share of CUs and bandwidth (step 74.0 ms vs
+  // 71.1 ms).  It sits on the critical path, so the launch is wide (65536 workgroups: 70.9 ms).  UNR (loads in flight per
+  // stream per lane) made no difference at 1, 2, 4.
+  for (long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += stride * UNR) {
+    f32x4 pv[UNR], gv[UNR], mv[UNR], vv[UNR];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float gr = gv[e] * gscale;
-      float pe = pv[e] * decay;
-      const float me = b1 * mv[e] + (1.f - b1) * gr;
-      const float ve = b2 * vv[e] + (1.f - b2) * gr * gr;
-      pe -= step_size * me / (sqrtf(ve) * inv_sqrt_bc2 + eps);
-      pv[e] = pe; mv[e] = me; vv[e] = ve;
+    for (int u = 0; u < UNR; ++u) {
+      const long i = i0 + u * stride;
+      if (i < n4) { pv[u] = ((f32x4*)p)[i]; gv[u] = ((f32x4*)g)[i]; mv[u] = ((f32x4*)m)[i]; vv[u] = ((f32x4*)v)[i]; }
     }
-    ((f32x4*)p)[i] = pv; ((f32x4*)m)[i] = mv; ((f32x4*)v)[i] = vv;
-    if (zero_grad) ((f32x4*)g)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (pb) ((u32x2*)pb)[i] = (u32x2){pack2bf(pv[0], pv[1]), pack2bf(pv[2], pv[3])};
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const long i = i0 + u * stride;
+      if (i >= n4) break;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float gr = gv[u][e] * gscale;
+        float pe = pv[u][e] * decay;
+        const float me = b1 * mv[u][e] + (1.f - b1) * gr;
+        const float ve = b2 * vv[u][e] + (1.f - b2) * gr * gr;
+        pe -= step_size * me / (sqrtf(ve) * inv_sqrt_bc2 + eps);
+        pv[u][e] = pe; mv[u][e] = me; vv[u][e] = ve;
+      }
+      ((f32x4*)p)[i] = pv[u]; ((f32x4*)m)[i] = mv[u]; ((f32x4*)v)[i] = vv[u];
+      if (zero_grad) ((f32x4*)g)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (pb) ((u32x2*)pb)[i] = (u32x2){pack2bf(pv[u][0], pv[u][1]), pack2bf(pv[u][2], pv[u][3])};
+    }
   }
 }
 
@@ -112,9 +130,13 @@ extern "C" int vacnic_adamw(const vacnic_adamw_args* a, void* stream) {
          VACNIC_MISALIGNED, "adamw: arenas must be 16-byte aligned");
   if (a->n == 0) return VACNIC_OK;
   const long n4 = a->n >> 2;
-  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n4)), dim3(256), 0, (hipStream_t)stream, a->p, a->g, a->m, a->v,
-                     (bf16_t*)a->p_bf16, a->hyper, n4, a->beta1, a->beta2, a->eps, a->weight_decay, a->grad_scale,
-                     a->zero_grad, a->clip_coef);
+  unsigned blocks = 65536;                     // wide launch (see the kernel comment); small arenas: one element per thread
+  const long need = (n4 + 255) / 256;
+  if (const char* e = getenv("VACNIC_ADAMW_BLOCKS")) { const long bb = atol(e); if (bb > 0) blocks = (unsigned)bb; }   // A/B knob
+  if (need < blocks) blocks = (unsigned)(need < 1 ? 1 : need);
+  hipLaunchKernelGGL(adamw_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a->p, a->g, a->m, a->v,
+                     (bf16_t*)a->p_bf16, a->hyper, n4, a->beta1, a->beta2, a->eps, a->weight_decay, a->grad_scale, a->zero_grad,
+                     a->clip_coef);
   VLAUNCH_CHECK();
   return VACNIC_OK;
 }
