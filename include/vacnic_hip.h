@@ -58,10 +58,16 @@ enum { VACNIC_ACT_NONE = 0, VACNIC_ACT_GELU = 1, VACNIC_ACT_TANH = 2, VACNIC_ACT
  *   residual       optional bf16 [M][ldo] added after the activation.
  *   out_mode       0: bf16 store, 1: f32 store, 2: f32 atomic accumulate (out += ..; split-K ok)
  *   split_k        >=1; >1 requires out_mode 2.
+ * With out_mode 0 and 256-row tiles the result is rounded to bf16 once (bias and a plain activation are applied in
+ * fp32 first); a saved pre-activation, the fused activation backward and the residual are then applied to that bf16
+ * value — the arithmetic of a bf16 Linear followed by a bf16 elementwise op.
  */
 typedef struct {
   const void* x; const void* w; const float* bias;
   void* out; void* preact; const void* dact_src; const void* residual;
+  float* xsum;                    /* optional f32 [M]: xsum[m] += sum_k X(m,k), not scaled by alpha — the bias gradient
+                                     (column sums of dY) fused into the weight-gradient GEMM that stages dY anyway
+                                     (replaces the separate reduction autograd runs for nn.Linear.bias, MFULL:449-452) */
   int64_t M, N, K;
   int64_t ldx, ldw, ldo;
   int32_t x_kstrided, w_kstrided;
@@ -127,6 +133,9 @@ typedef struct {
   const float* mean; const float* rstd;
   void* dresidual; void* dx; float* dgamma; float* dbeta;
   int64_t R, D; float p_drop; uint64_t seed; const uint64_t* seed_dev;
+  float* partials; int64_t partial_rows;   /* optional caller-owned scratch f32 [partial_rows][2][D] (partial_rows >= min(1024,
+                                              ceil(R/4))): dgamma/dbeta are then reduced in two stages (per-block column sums,
+                                              one small fold) instead of ~1000 same-address atomics per column */
 } vacnic_add_ln_bwd_args;
 int vacnic_add_ln_bwd(const vacnic_add_ln_bwd_args* a, void* stream);
 

@@ -148,6 +148,87 @@ def test_gemm_all_layouts_both_tile_configs(K, hint, M, N, K_):
     close(K.gemm(xt, w, M, N, K_, ldx=xt.shape[1], x_kstrided=True, tile_hint=hint), ref, 1e-2, tol, f"TN hint {hint}")
 
 
+@pytest.mark.parametrize("M,N,K_", [(16384, 1024, 1024), (16384, 4096, 1024)])
+def test_gemm_target_shapes_elementwise(K, M, N, K_):
+    """BASELINE target shapes at full M (the 'BART cross-attn GEMM' M=B*S=16384, N=K=1024 and the FFN up-projection) —
+    every element against an fp32 product, in all three layouts of the step (forward NN, dgrad NT, wgrad TT)."""
+    x = rnd(M, K_, seed=1); w = rnd(N, K_, scale=0.05, seed=2); b = rnd(N, dtype=torch.float32, seed=3)
+    ref = x.float() @ w.float().t()
+    tol = 2e-2 * math.sqrt(K_ / 64) * 0.3
+    close(K.gemm(x, w, M, N, K_, bias=b), ref + b, 1e-2, tol, "NN")
+    wt = w.t().contiguous()
+    close(K.gemm(x, wt, M, N, K_, w_kstrided=True), ref, 1e-2, tol, "NT")
+    del ref
+    # wgrad: dW[N, K_] = dY[M, N]^T X[M, K_]  (reduction over the 16384 rows, split-K atomics into an fp32 arena view)
+    dy = rnd(M, N, scale=0.1, seed=4)
+    acc = torch.zeros(N, K_, device="cuda")
+    bsum = torch.zeros(N, device="cuda")
+    K.gemm(dy, x, N, K_, M, out=acc, ldx=N, ldw=K_, ldo=K_, x_kstrided=True, w_kstrided=True, out_mode=2,
+           split_k=K.wgrad_split(M, ((N + 127) // 128) * ((K_ + 127) // 128)), xsum=bsum)
+    close(acc, dy.float().t() @ x.float(), 2e-3, 2e-2 * math.sqrt(M / 256), "TT")
+    close(bsum, dy.float().sum(0), 2e-3, 2e-2 * math.sqrt(M / 256), "TT fused bias gradient")
+
+
+@pytest.mark.parametrize("hint", [256, 264, 256 + 64000, 256 + 16000])
+def test_gemm_persistent_many_tiles_and_ragged_rows(K, hint):
+    """more tiles than CUs (the persistent work loop wraps: 65 x 5 = 325 tiles of 256x256) with a ragged last row block;
+    hint + 64000 = one workgroup per tile, + 16000 = fp32 staged epilogue: all must agree with the fp32 product."""
+    M, N, K_ = 16384 + 100, 1280, 192
+    x = rnd(M, K_, seed=1); w = rnd(N, K_, scale=0.1, seed=2); b = rnd(N, dtype=torch.float32, seed=3); res = rnd(M, N, seed=4)
+    ref = x.float() @ w.float().t() + b
+    out = torch.full((M + 8, N), 7.0, device="cuda", dtype=torch.bfloat16)
+    K.gemm(x, w, M, N, K_, bias=b, out=out, tile_hint=hint)
+    close(out[:M], ref, 1e-2, 2e-2, f"plain hint {hint}")
+    assert (out[M:] == 7.0).all(), "rows >= M must not be written"
+    close(K.gemm(x, w, M, N, K_, bias=b, residual=res, tile_hint=hint), ref + res.float(), 1e-2, 3e-2, f"residual hint {hint}")
+
+
+@pytest.mark.parametrize("act", ["gelu", "tanh", "quick_gelu"])
+@pytest.mark.parametrize("hint", [256, 264])
+def test_gemm_epilogues_bf16_staged_256_row_tiles(K, act, hint):
+    """the single-pass bf16 epilogue of the 256-row tiles: activation, saved pre-activation, residual, fused activation
+    backward (on the saved pre-activation), strided output rows."""
+    M, N, K_ = 700, 520, 128
+    x = rnd(M, K_, seed=1); w = rnd(N, K_, scale=0.1, seed=2); b = rnd(N, dtype=torch.float32, seed=3)
+    res = rnd(M, N, seed=4)
+    f = {"gelu": torch.nn.functional.gelu, "tanh": torch.tanh, "quick_gelu": lambda t: t * torch.sigmoid(1.702 * t)}[act]
+    u = x.float() @ w.float().t() + b
+    close(K.gemm(x, w, M, N, K_, bias=b, act=act, tile_hint=hint), f(u), 1e-2, 1e-2, "act only (in registers)")
+    pre = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ld = 528
+    out = torch.full((M, ld), 3.0, device="cuda", dtype=torch.bfloat16)
+    out2 = K.gemm(x, w, M, N, K_, bias=b, act=act, preact=pre, tile_hint=hint)             # bf16 path, saved pre-activation
+    close(pre, u, 1e-2, 1e-2, "preact")
+    close(out2, f(pre.float()), 1e-2, 1e-2, f"act {act} on the saved pre-activation")
+    close(out2, f(u), 1.5e-2, 2e-2, f"act {act} vs fp32")
+    close(K.gemm(x, w, M, N, K_, bias=b, act=act, residual=res, tile_hint=hint), f(u) + res.float(), 1e-2, 2e-2, "act + residual")
+    pre2 = torch.empty_like(pre)                                                             # two extras: fp32-staged path
+    out3 = K.gemm(x, w, M, N, K_, bias=b, act=act, preact=pre2, residual=res, tile_hint=hint)
+    close(pre2, u, 1e-2, 1e-2, "preact (with residual)")
+    close(out3, f(u) + res.float(), 1e-2, 2e-2, f"act {act} + preact + residual")
+    K.gemm(x, w, M, N, K_, bias=b, out=out, ldo=ld, tile_hint=hint)
+    close(out[:, :N], u, 1e-2, 1e-2, "padded ldo"); assert (out[:, N:] == 3.0).all()
+    dy = rnd(M, 96, seed=5); w2 = rnd(96, N, scale=0.1, seed=6)
+    du = K.gemm(dy, w2, M, N, 96, w_kstrided=True, act=act, dact_src=pre, tile_hint=hint)
+    uu = pre.float().requires_grad_(True)
+    f(uu).backward(dy.float() @ w2.float())
+    close(du, uu.grad, 2e-2, 2e-2, f"dact {act}")
+
+
+@pytest.mark.parametrize("hint", [0, 64, 128, 256, 264, 261])
+@pytest.mark.parametrize("M,N,K_,split", [(1024, 1024, 2048, 1), (1024, 768, 4096, 4), (200, 520, 1000, 2), (80, 80, 4096, 8)])
+def test_gemm_wgrad_fused_bias_gradient(K, hint, M, N, K_, split):
+    """xsum: column sums of dY (the nn.Linear bias gradient) out of the weight-gradient GEMM's own fragments."""
+    ldy = (M + 7) // 8 * 8
+    dy = rnd(K_, ldy, seed=1); dy[:, M:] = 0
+    x = rnd(K_, N, seed=2)
+    acc = torch.ones(M, N, device="cuda")
+    bs = torch.full((M,), 0.5, device="cuda")
+    K.gemm(dy, x, M, N, K_, out=acc, ldx=ldy, x_kstrided=True, w_kstrided=True, out_mode=2, split_k=split, xsum=bs, tile_hint=hint)
+    close(acc, 1.0 + dy[:, :M].float().t() @ x.float(), 2e-3, 2e-2 * math.sqrt(K_ / 256), "wgrad")
+    close(bs, 0.5 + dy[:, :M].float().sum(0), 2e-3, 2e-2 * math.sqrt(K_ / 256), f"bias gradient hint {hint} split {split}")
+
+
 # ------------------------------------------------------------------------------------------- attention
 def attn_ref(q, k, v, key_mask, causal, scale):
     B, Tq, H, hd = q.shape

@@ -35,7 +35,7 @@ def _struct(name, fields):
 
 
 GemmArgs = _struct("vacnic_gemm_args", [
-    ("x", vp), ("w", vp), ("bias", vp), ("out", vp), ("preact", vp), ("dact_src", vp), ("residual", vp),
+    ("x", vp), ("w", vp), ("bias", vp), ("out", vp), ("preact", vp), ("dact_src", vp), ("residual", vp), ("xsum", vp),
     ("M", i64), ("N", i64), ("K", i64), ("ldx", i64), ("ldw", i64), ("ldo", i64),
     ("x_kstrided", i32), ("w_kstrided", i32), ("act", i32), ("out_mode", i32), ("split_k", i32), ("alpha", f32), ("tile_hint", i32)])
 
@@ -62,7 +62,7 @@ AddLnFwdArgs = _struct("vacnic_add_ln_fwd_args", [
 AddLnBwdArgs = _struct("vacnic_add_ln_bwd_args", [
     ("dout", vp), ("x", vp), ("residual", vp), ("gamma", vp), ("mean", vp), ("rstd", vp),
     ("dresidual", vp), ("dx", vp), ("dgamma", vp), ("dbeta", vp),
-    ("R", i64), ("D", i64), ("p_drop", f32), ("seed", u64), ("seed_dev", vp)])
+    ("R", i64), ("D", i64), ("p_drop", f32), ("seed", u64), ("seed_dev", vp), ("partials", vp), ("partial_rows", i64)])
 
 EmbedLnFwdArgs = _struct("vacnic_embed_ln_fwd_args", [
     ("ids", vp), ("embed", vp), ("pos", vp), ("gamma", vp), ("beta", vp), ("out", vp), ("mean", vp), ("rstd", vp),

@@ -1,0 +1,871 @@
+// gemm_kernel.h — the MFMA GEMM kernel template of libvacnic_hip.so (see gemm.hip for the design notes and the host-side
+// dispatch).  Included by gemm.hip and by the gemm_t*.hip translation units, each of which instantiates ONE tile
+// configuration (four operand layouts) so that the configurations compile in parallel.
+#pragma once
+#include "common.h"
+#include <stdlib.h>
+
+namespace vacgemm {
+
+
+constexpr int BK = 64;
+constexpr int OOB = 0x7ffffff0;               // voffset beyond any (<2 GiB) buffer -> load returns 0
+
+struct GemmP {
+  const bf16_t* x; const bf16_t* w; const float* bias;
+  void* out; bf16_t* preact; const bf16_t* dact_src; const bf16_t* residual;
+  float* xsum;          // optional f32 [M]: xsum[m] += sum_k X(m,k)  (bias gradient fused into the weight-gradient GEMM)
+  int M, N, K;
+  int ldx, ldw, ldo;
+  int act, out_mode, split_k, k_per_split;
+  float alpha;
+  unsigned x_bytes, w_bytes;
+  int tiles_m, tiles_n;
+  int debug;            // profiling aid (tile_hint >= 1000): bit0 skip the global stores, bit1 skip the K loop, bit2 skip the epilogue, bit3 return at once, bit4 fp32 staged epilogue, bit5 no LDS-DMA in the loop, bit6 one workgroup per tile (not persistent), bit7 no fragment reads
+};
+
+// f(k) of the K-strided swizzle: distinct for the 8 k-rows one tr-read half touches.
+__device__ __forceinline__ int fk(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+
+// Issue this wave's LDS-DMA loads for one operand tile of ROWS rows x BKT k (BKT = 64 or 32).
+//   KS=false, BKT=64: tile [ROWS][64 k], 128-B LDS rows, chunk' = chunk ^ (row & 7); one 1-KiB piece = 8 rows
+//   KS=false, BKT=32: two 64-B global rows share one 128-B LDS row R = row/2 (chunk = (row&1)*4 + kchunk),
+//                     chunk' = chunk ^ (R & 7); one piece = 16 rows
+//   KS=true : tile [BKT k][ROWS], 2*ROWS-B rows, chunk' = chunk ^ swz(k); one piece = 512/ROWS k-rows
+template <bool KS, int ROWS, int BKT, int NWAVE>
+__device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, int r0, int R,
+                                           int k0, int kend, int ld, int wave, int lane) {
+  constexpr int PIECES = ROWS * BKT * 2 / 1024 / NWAVE;      // 1-KiB pieces per wave
+  static_assert(PIECES >= 1, "tile too small for this wave count");
+#pragma unroll
+  for (int i = 0; i < PIECES; ++i) {
+    const int blk = wave * PIECES + i;
+    int voff;
+    if (!KS) {
+      int row, kch;
+      if (BKT == 64) {
+        row = blk * 8 + (lane >> 3);
+        kch = (lane & 7) ^ (row & 7);
+      } else {
+        const int Rl = blk * 8 + (lane >> 3);
+        const int lc = (lane & 7) ^ (Rl & 7);
+        row = 2 * Rl + (lc >> 2);
+        kch = lc & 3;
+      }
+      const int gr = r0 + row, gk = k0 + kch * 8;
+      voff = (gr < R && gk < kend) ? (int)(((unsigned)gr * (unsigned)ld + (unsigned)gk) * 2u) : OOB;
+    } else {
+      constexpr int LPR = ROWS / 8;             // lanes (16-B chunks) per k-row
+      const int k = blk * (64 / LPR) + lane / LPR;
+      const int lc = (lane % LPR) ^ ((fk(k) << 1) & (LPR - 1));   // 64-row tiles have only 8 chunks per k-row
+      const int gk = k0 + k, gr = r0 + lc * 8;
+      voff = (gk < kend && gr < R) ? (int)(((unsigned)gk * (unsigned)ld + (unsigned)gr) * 2u) : OOB;
+    }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + blk * 1024), 16, voff, 0, 0, 0);
+  }
+}
+
+// Fragment for MFMA 16x16x32: lane l gets element (row = rbase + (l&15), k = kk*32 + 8*(l>>4) + j), j=0..7.
+template <bool KS, int ROWS, int BKT>
+__device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int rbase, int kk, int lane) {
+  if (!KS) {
+    const int row = rbase + (lane & 15);
+    if (BKT == 64) {
+      const int chunk = kk * 4 + (lane >> 4);
+      return *(const bf16x8*)(lds_tile + row * 128 + ((chunk ^ (row & 7)) << 4));
+    } else {
+      const int Rl = row >> 1;
+      const int chunk = (row & 1) * 4 + (lane >> 4);
+      return *(const bf16x8*)(lds_tile + Rl * 128 + ((chunk ^ (Rl & 7)) << 4));
+    }
+  } else {
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const int chunk = (rbase >> 3) + (p >> 1);
+    bf16x8 r;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int k = kk * 32 + 8 * g + 4 * hh + q;
+      const int phys = chunk ^ ((fk(k) << 1) & (ROWS / 8 - 1));
+      const char* a = lds_tile + k * (ROWS * 2) + phys * 16 + (p & 1) * 8;
+      bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)LDS_PTR(a));
+      r[4 * hh + 0] = t[0]; r[4 * hh + 1] = t[1]; r[4 * hh + 2] = t[2]; r[4 * hh + 3] = t[3];
+    }
+    return r;
+  }
+}
+
+// Epilogue on 8 consecutive outputs of one row (read back from the LDS-staged C tile): bias, saved
+// pre-activation, activation or fused activation-backward, residual, then a 16-byte (bf16) /
+// 2x16-byte (f32) store or 8 f32 atomics on 32 contiguous bytes.
+__device__ __forceinline__ void load8bf(const bf16_t* p, float v[8]) {
+  u32x4 r = *(const u32x4*)p;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(r[i] << 16); v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u); }
+}
+__device__ __forceinline__ void store8bf(bf16_t* p, const float v[8]) {
+  *(u32x4*)p = (u32x4){pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+}
+
+__device__ __forceinline__ void unpack8bf(u32x4 r, float v[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(r[i] << 16); v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u); }
+}
+
+// 8 consecutive, fully in-range, 16-byte-aligned outputs of one row.  Bias and the raw residual / activation-source words
+// were loaded by the caller (batched over all of a thread's chunks, so their latency overlaps).
+__device__ __forceinline__ void epilogue8_vec(const GemmP& p, float v[8], size_t off, const float bia[8], u32x4 rraw, u32x4 draw) {
+  if (p.alpha != 1.0f) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= p.alpha;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] += bia[j];
+  if (p.preact) store8bf(p.preact + off, v);
+  if (p.dact_src) {
+    float d[8];
+    unpack8bf(draw, d);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= act_bwd(p.act, d[j]);
+  } else if (p.act != VACNIC_ACT_NONE) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = act_fwd(p.act, v[j]);
+  }
+  if (p.residual) {
+    float d[8];
+    unpack8bf(rraw, d);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += d[j];
+  }
+  if (p.debug & 1) {
+    if (v[0] == 12345.678f) ((bf16_t*)p.out)[off] = 0;
+  } else if (p.out_mode == 0) {
+    store8bf((bf16_t*)p.out + off, v);
+  } else if (p.out_mode == 1) {
+    float* o = (float*)p.out + off;
+    *(f32x4*)o = (f32x4){v[0], v[1], v[2], v[3]};
+    *(f32x4*)(o + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+  } else {
+    float* o = (float*)p.out + off;
+    f32x4 a0 = *(f32x4*)o, a1 = *(f32x4*)(o + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a0[j] += v[j]; a1[j] += v[4 + j]; }
+    *(f32x4*)o = a0; *(f32x4*)(o + 4) = a1;
+  }
+}
+
+__device__ __forceinline__ void epilogue8(const GemmP& p, float v[8], int m, int n, bool add_bias, bool vec_ok) {
+  const size_t off = (size_t)m * p.ldo + n;
+  const int nv = min(8, p.N - n);
+  const bool vec = vec_ok && nv == 8;
+  if (p.alpha != 1.0f) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= p.alpha;
+  }
+  if (p.bias && add_bias) {
+    if (nv == 8) {
+      const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);   // arena slots are 16-byte aligned, n % 8 == 0
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[j] += b0[j]; v[4 + j] += b1[j]; }
+    } else {
+      for (int j = 0; j < nv; ++j) v[j] += p.bias[n + j];
+    }
+  }
+  if (p.preact) {
+    if (vec) store8bf(p.preact + off, v);
+    else for (int j = 0; j < nv; ++j) p.preact[off + j] = f2bf(v[j]);
+  }
+  if (p.dact_src) {
+    float d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (vec) load8bf(p.dact_src + off, d);
+    else for (int j = 0; j < nv; ++j) d[j] = bf2f(p.dact_src[off + j]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= act_bwd(p.act, d[j]);
+  } else if (p.act != VACNIC_ACT_NONE) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = act_fwd(p.act, v[j]);
+  }
+  if (p.residual) {
+    float d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (vec) load8bf(p.residual + off, d);
+    else for (int j = 0; j < nv; ++j) d[j] = bf2f(p.residual[off + j]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += d[j];
+  }
+  if (p.debug & 1) {
+    if (v[0] == 12345.678f) ((bf16_t*)p.out)[off] = 0;      // keeps the values live, never true in practice
+  } else if (p.out_mode == 0) {
+    bf16_t* o = (bf16_t*)p.out + off;
+    if (vec) store8bf(o, v);
+    else for (int j = 0; j < nv; ++j) o[j] = f2bf(v[j]);
+  } else if (p.out_mode == 1) {
+    float* o = (float*)p.out + off;
+    if (nv == 8 && (p.ldo & 3) == 0) {
+      *(f32x4*)o = (f32x4){v[0], v[1], v[2], v[3]};
+      *(f32x4*)(o + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+    } else {
+      for (int j = 0; j < nv; ++j) o[j] = v[j];
+    }
+  } else {
+    // accumulate, single K-split: no other workgroup of this launch touches these outputs -> vector read-modify-write
+    float* o = (float*)p.out + off;
+    if (nv == 8 && (p.ldo & 3) == 0) {
+      f32x4 a0 = *(f32x4*)o, a1 = *(f32x4*)(o + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { a0[j] += v[j]; a1[j] += v[4 + j]; }
+      *(f32x4*)o = a0; *(f32x4*)(o + 4) = a1;
+    } else {
+      for (int j = 0; j < nv; ++j) o[j] += v[j];
+    }
+  }
+}
+
+template <int V> struct IC { static constexpr int value = V; };
+
+#define VAC_OPAQUE_S(x) asm volatile("" : "+s"(x))
+
+template <int N>
+__device__ __forceinline__ void wait_vm_lgkm() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
+
+// Workgroup barrier that orders LDS traffic only: this wave's LDS operations are retired, global stores and LDS-DMA stay in
+// flight (a __syncthreads() here would also drain the store burst of the epilogue it separates from the next tile's loads).
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+template <int BM, int BN, int WM, int WN, int BKT, int NSTAGE, bool PIPE, bool XKS, bool WKS>
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
+  constexpr int NWAVE = WM * WN, NTHR = 64 * NWAVE;
+  constexpr int TM = BM / WM, TN = BN / WN;             // per-wave output sub-tile
+  constexpr int FA = TM / 16, FB = TN / 16;             // MFMA tiles per wave along m / n
+  constexpr int XT = BM * BKT * 2, WT = BN * BKT * 2, STAGE = XT + WT;
+  constexpr bool PINGPONG = PIPE && BKT == 32 && NSTAGE == 4;
+  constexpr int XSN = FA / WN;                           // row-sum accumulators per wave (xsum)
+  static_assert(FA % WN == 0 && FA / WN <= 4, "xsum: row blocks split over the waves of a row group, <= 4 each");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (p.debug & 8) return;
+
+  __amdgpu_buffer_rsrc_t xs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+
+  // K-strided operands may read up to round_up(R, 8) columns of a row (host guarantees ld covers it)
+  const int RX = XKS ? ((p.M + 7) & ~7) : p.M;
+  const int RW = WKS ? ((p.N + 7) & ~7) : p.N;
+
+  // ---- work loop.  The ping-pong configurations are launched PERSISTENT (one workgroup per CU, grid = #CUs): workgroup L
+  // takes work items L, L + grid, ...; the global stores of tile i are still draining (HBM-write bound: a round of 256
+  // tiles leaves 32 MiB at once) while tile i+1 loads and multiplies.  Every other configuration is launched with one
+  // workgroup per work item and runs this loop once.
+  // XCD-aware work order.  Workgroup L of the 1-D grid runs on XCD L % 8, each with its own 4 MiB L2 (grid % 8 == 0 when
+  // persistent, so a workgroup stays on "its" XCD run for all its items).
+  //  * split-K launches (weight gradients): split z = L % nsplit, so one XCD (or nsplit/8 .. 8/nsplit of them) owns a whole
+  //    K-slice and every row of dY / X in it is fetched once — all tiles of a slice run concurrently on that XCD
+  //    (+2 % on the wgrad GEMMs; with the splits in blockIdx.z every XCD touched every K-slice).
+  //  * otherwise each XCD gets a contiguous run of tiles (bijective for any tile count), n fastest so neighbours reuse the
+  //    same X panel in their L2.  (Walking 4-column strips inside a run — an 8 x 4 block of tiles in flight instead of
+  //    2 x 16 — measured no gain: the 256 MiB memory-side cache already absorbs the W re-reads.)
+  const int nt = p.tiles_m * p.tiles_n;
+  const int total = nt * p.split_k;
+  struct Work { int m0, n0, kbeg, kend, tn, zsplit; };
+  auto coords = [&](int v) {
+    Work k;
+    int bid = v;
+    k.zsplit = 0;
+    if (p.split_k > 1) {
+      k.zsplit = bid % p.split_k;
+      bid = bid / p.split_k;
+    } else {
+      const int q = nt >> 3, r = nt & 7, xcd = bid & 7;
+      bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tm = bid / p.tiles_n;
+    k.tn = bid - tm * p.tiles_n;
+    k.m0 = tm * BM; k.n0 = k.tn * BN;
+    k.kbeg = k.zsplit * p.k_per_split;
+    k.kend = min(p.K, k.kbeg + p.k_per_split);
+    return k;
+  };
+  // LDS: NSTAGE-deep ring, stage s at smem + s*STAGE = {X tile, W tile}.  Tiles t+1 .. t+NSTAGE-1 are in flight
+  // while tile t is multiplied; one barrier per K-tile.  Loads are issued unconditionally (a tile past kend is
+  // all out-of-range -> zero fill, never read) so the counted vmcnt below is a compile-time constant.
+  constexpr int LOADS = (BM + BN) * BKT * 2 / 1024 / NWAVE;   // LDS-DMA instructions per wave per K-tile
+  static_assert(LOADS * (NSTAGE - 2) <= 63, "vmcnt immediate");
+  constexpr bool PIPED = PIPE && BKT == 64 && NSTAGE == 2;
+  constexpr int PRO = PIPED ? 2 : NSTAGE - 1;            // tiles staged before the loop
+  auto prologue = [&](const Work& k, int wave_, int lane_) {
+#pragma unroll
+    for (int s = 0; s < PRO; ++s) {
+      stage_tile<XKS, BM, BKT, NWAVE>(xs, smem + s * STAGE, k.m0, RX, k.kbeg + s * BKT, k.kend, p.ldx, wave_, lane_);
+      stage_tile<WKS, BN, BKT, NWAVE>(ws, smem + s * STAGE + XT, k.n0, RW, k.kbeg + s * BKT, k.kend, p.ldw, wave_, lane_);
+    }
+  };
+  // bf16 epilogue geometry (256-row tiles): 16-byte chunks per staged row, rows per sweep of the workgroup, sweeps (= 16-byte
+  // global stores per thread) per tile
+  constexpr int ROWB = BN * 2, NCH = ROWB / 16, RSTEP = NTHR / NCH, NIT = BM / RSTEP;
+  static_assert(!PINGPONG || 2 * LOADS + 2 * NIT <= 63, "vmcnt immediate (stores in flight behind the next tile's loads)");
+  int vb = blockIdx.x;
+  if (vb >= total) return;
+  Work wk = coords(vb);
+  prologue(wk, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), threadIdx.x & 63);
+  // `pend`: global stores of the previous tile's epilogue that this wave issued AFTER this tile's prologue loads (0, NIT or
+  // 2*NIT; exactly that many wave-instructions, buffer stores never skip).  vmcnt counts loads and stores together in issue
+  // order, so until those stores have retired the waits for the first stages allow `pend` more operations in flight —
+  // the store burst of tile i (HBM-write bound) drains behind the first K-steps of tile i+1 instead of in front of them.
+  int pend = 0;
+  for (;;) {
+  // per-lane indices are re-derived from an opaque copy of the thread index for every work item (and once more for the
+  // epilogue): otherwise every per-lane address of the K loop AND of the epilogue is hoisted out of the work loop and
+  // kept live across both, which does not fit the 256-VGPR budget of the 8-wave tiles
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % WM, wn = wave / WM;
+  const int lm = lane & 15;
+  const int zsplit = wk.zsplit, tn = wk.tn;
+  const int m0 = wk.m0, n0 = wk.n0;
+  const int kbeg = wk.kbeg, kend = wk.kend;
+  const int ntile = (p.debug & 2) ? 0 : (kend - kbeg + BKT - 1) / BKT;
+
+  f32x4 acc[FB][FA];
+#pragma unroll
+  for (int b = 0; b < FB; ++b)
+#pragma unroll
+    for (int a = 0; a < FA; ++a) acc[b][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // xsum[m] += sum_k X(m,k) (the bias gradient of a weight-gradient GEMM: X = dY; compiled into the both-K-strided layout
+  // only).  One extra MFMA per 16 rows re-uses the X fragments that are in registers anyway: the A operand is a row
+  // selector (row i all ones, the other rows zero), so the XSN row blocks a wave is responsible for land in rows 0..XSN-1
+  // of ONE extra accumulator tile.  The K-steps are dealt round-robin to the tiles_n workgroups that share this row panel
+  // and the FA row blocks to the WN waves that hold the same fragments, so the extra matrix work is 1/(WN*FB*tiles_n) of
+  // the tile's — and the separate pass over dY is gone.
+  constexpr bool XS = XKS && WKS;
+  const bool xs_on = XS && p.xsum != nullptr;
+  int xs_next = tn;
+  f32x4 accs = (f32x4){0.f, 0.f, 0.f, 0.f};
+#define VAC_XSUM_MFMA(XF)                                                                   \
+  if constexpr (XS) {                                                                       \
+    _Pragma("unroll") for (int w_ = 0; w_ < WN; ++w_)                                       \
+      if (wn == w_) {                                                                       \
+        _Pragma("unroll") for (int i = 0; i < XSN; ++i) {                                   \
+          const short o_ = lm == i ? (short)0x3F80 : (short)0;                              \
+          const bf16x8 sel_ = {o_, o_, o_, o_, o_, o_, o_, o_};                             \
+          accs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sel_, XF[w_ * XSN + i], accs, 0, 0, 0); \
+        }                                                                                   \
+      }                                                                                     \
+  }
+#define VAC_XSUM(XF, STEP)                                                                  \
+  if (XS && xs_on && (STEP) == xs_next) {                                                   \
+    VAC_XSUM_MFMA(XF)                                                                       \
+    xs_next += p.tiles_n;                                                                   \
+  }
+
+  // tile 0 landed (this wave's pieces; the stores counted in `pend` are younger than all prologue loads)
+  if (PINGPONG && pend == NIT) wait_vm_lgkm<LOADS * (PRO - 1) + NIT>();
+  else if (PINGPONG && pend != 0) wait_vm_lgkm<LOADS * (PRO - 1) + 2 * NIT>();
+  else wait_vm_lgkm<LOADS * (PRO - 1)>();
+  __builtin_amdgcn_s_barrier();
+  int cur = 0, nxt = NSTAGE - 1;
+  if constexpr (PINGPONG) {
+    // Ping-pong K loop (8 waves, two per SIMD; 32-wide K stages in a 4-slot ring).  The waves of a workgroup form two
+    // groups, A = waves 0..3 and B = waves 4..7 (SIMD partners), that run the same sequence one interval apart:
+    //     A:  MEM(0) | COMP(0) | MEM(1) | COMP(1) | ...
+    //     B:    -    | MEM(0)  | COMP(0)| MEM(1)  | ...          ('|' = workgroup barrier)
+    // MEM(h)  = 12 ds_read_b128 (the fragments of stage h) + this wave's 4 LDS-DMA pieces of stage h+3 + counted wait,
+    // COMP(h) = 32 back-to-back MFMAs.  In every interval one wave per SIMD owns the matrix pipe while its partner owns the
+    // LDS / vector-memory issue ports, so neither the fragment reads nor the ~60-100-cycle issue cost of an LDS-DMA piece
+    // ever stalls the MFMA stream (measured before: MFMA-only loop 1.0 us per 64-K, +0.27 us for the LDS reads, +0.34 us
+    // for the DMA issue when both partners do the same thing at the same time).
+    // Ring safety: stage j is read by A in interval 2j and by B in interval 2j+1; MEM(j+1) (intervals 2j+2 / 2j+3) refills
+    // its slot with stage j+4.  A wave leaves MEM(h) only when its own pieces of stage h+1 have landed (vmcnt(8): stages
+    // h+2, h+3 may fly), and a barrier separates that from every later reader.
+    static_assert(NWAVE == 8 && LOADS >= 2, "ping-pong loop is written for 8 waves (two per SIMD)");
+    // (Issuing part of the DMA pieces in the middle of COMP(h) instead, or staggering the partners' issue points in a 64-wide
+    // pipelined loop, measured the same within noise: profiles/r1_gemm_overhead.txt.)
+    const bool grp_b = wave >= NWAVE / 2;
+    const int nst = ntile;
+    bf16x8 xf[FA], wf[FB];
+    if (grp_b) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+    int rd = 0, wr = 3;
+    for (int h = 0; h < nst; ++h) {
+      const char* xr = smem + rd * STAGE;
+      char* xw = smem + wr * STAGE;
+      if (!(p.debug & 128) || h == 0) {
+#pragma unroll
+        for (int a = 0; a < FA; ++a) xf[a] = read_frag<XKS, BM, BKT>(xr, wm * TM + a * 16, 0, lane);
+#pragma unroll
+        for (int b = 0; b < FB; ++b) wf[b] = read_frag<WKS, BN, BKT>(xr + XT, wn * TN + b * 16, 0, lane);
+      }
+      if (!(p.debug & 32)) {
+        stage_tile<XKS, BM, BKT, NWAVE>(xs, xw, m0, RX, kbeg + (h + 3) * BKT, kend, p.ldx, wave, lane);
+        stage_tile<WKS, BN, BKT, NWAVE>(ws, xw + XT, n0, RW, kbeg + (h + 3) * BKT, kend, p.ldw, wave, lane);
+      }
+      // stage h+1 must have landed (this wave's pieces); newer ones may fly — and so may, during the first two steps, the
+      // previous tile's stores that were issued between this tile's prologue loads and the loads of stages 3 and 4
+      if (h < 2 && pend != 0) {
+        if (pend == NIT) wait_vm_lgkm<2 * LOADS + NIT>();
+        else wait_vm_lgkm<2 * LOADS + 2 * NIT>();
+      } else {
+        wait_vm_lgkm<2 * LOADS>();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int b = 0; b < FB; ++b)
+#pragma unroll
+        for (int a = 0; a < FA; ++a)
+          acc[b][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b], xf[a], acc[b][a], 0, 0, 0);
+      VAC_XSUM(xf, h)
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      rd = (rd + 1) & 3;
+      wr = (wr + 1) & 3;
+    }
+    if (!grp_b) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+  } else if constexpr (PIPED) {
+    // Software-pipelined K loop, two LDS slots.  Per tile t:
+    //   read frags (t, kk=1) | MFMA (t, kk=0) | wait tile t+1 landed + BARRIER | issue LDS-DMA of tile t+2 into slot t |
+    //   read frags (t+1, kk=0) | MFMA (t, kk=1)
+    // - the barrier sits in the middle of the tile's MFMA work: after it the LDS reads of the next tile (and the barrier
+    //   skew of the 8 waves) are covered by the 32..64 MFMAs of (t, kk=1);
+    // - at the barrier every fragment of tile t is already in registers, so slot t is free: the loads of tile t+2 are
+    //   issued right behind it and have a FULL iteration to land (a 64 KiB tile needs ~0.9 us at the per-CU L2->LDS rate
+    //   plus latency; a load issued half an iteration before its wait stalls the whole workgroup);
+    bf16x8 xf0[FA], wf0[FB], xf1[FA], wf1[FB];
+#pragma unroll
+    for (int a = 0; a < FA; ++a) xf0[a] = read_frag<XKS, BM, BKT>(smem, wm * TM + a * 16, 0, lane);
+#pragma unroll
+    for (int b = 0; b < FB; ++b) wf0[b] = read_frag<WKS, BN, BKT>(smem + XT, wn * TN + b * 16, 0, lane);
+    for (int t = 0; t < ntile; ++t) {
+      char* xcur = smem + cur * STAGE;
+      char* wcur = xcur + XT;
+#pragma unroll
+      for (int a = 0; a < FA; ++a) xf1[a] = read_frag<XKS, BM, BKT>(xcur, wm * TM + a * 16, 1, lane);
+#pragma unroll
+      for (int b = 0; b < FB; ++b) wf1[b] = read_frag<WKS, BN, BKT>(wcur, wn * TN + b * 16, 1, lane);
+#pragma unroll
+      for (int b = 0; b < FB; ++b)
+#pragma unroll
+        for (int a = 0; a < FA; ++a)
+          acc[b][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[b], xf0[a], acc[b][a], 0, 0, 0);
+      if (XS && xs_on && t == xs_next) { VAC_XSUM_MFMA(xf0) }
+      // tile t+1 landed (all of this wave's loads), every LDS read of slot t retired
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      stage_tile<XKS, BM, BKT, NWAVE>(xs, xcur, m0, RX, kbeg + (t + 2) * BKT, kend, p.ldx, wave, lane);
+      stage_tile<WKS, BN, BKT, NWAVE>(ws, wcur, n0, RW, kbeg + (t + 2) * BKT, kend, p.ldw, wave, lane);
+      cur ^= 1;
+      {
+        const char* xn = smem + cur * STAGE;           // tile t+1 (zero-filled past the end: harmless)
+#pragma unroll
+        for (int a = 0; a < FA; ++a) xf0[a] = read_frag<XKS, BM, BKT>(xn, wm * TM + a * 16, 0, lane);
+#pragma unroll
+        for (int b = 0; b < FB; ++b) wf0[b] = read_frag<WKS, BN, BKT>(xn + XT, wn * TN + b * 16, 0, lane);
+      }
+#pragma unroll
+      for (int b = 0; b < FB; ++b)
+#pragma unroll
+        for (int a = 0; a < FA; ++a)
+          acc[b][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[b], xf1[a], acc[b][a], 0, 0, 0);
+      VAC_XSUM(xf1, t)
+    }
+  } else {
+  bf16x8 xf[FA], wf[FB];
+  for (int t = 0; t < ntile; ++t) {
+    char* xcur = smem + cur * STAGE;
+    char* wcur = xcur + XT;
+    if (!(p.debug & 32)) {
+      // ring slot `nxt` was last read in iteration t-1 and every wave has passed that iteration's barrier
+      char* xnext = smem + nxt * STAGE;
+      stage_tile<XKS, BM, BKT, NWAVE>(xs, xnext, m0, RX, kbeg + (t + NSTAGE - 1) * BKT, kend, p.ldx, wave, lane);
+      stage_tile<WKS, BN, BKT, NWAVE>(ws, xnext + XT, n0, RW, kbeg + (t + NSTAGE - 1) * BKT, kend, p.ldw, wave, lane);
+    }
+#pragma unroll
+    for (int kk = 0; kk < BKT / 32; ++kk) {
+      if (!(p.debug & 128) || t == 0) {
+#pragma unroll
+        for (int a = 0; a < FA; ++a) xf[a] = read_frag<XKS, BM, BKT>(xcur, wm * TM + a * 16, kk, lane);
+#pragma unroll
+        for (int b = 0; b < FB; ++b) wf[b] = read_frag<WKS, BN, BKT>(wcur, wn * TN + b * 16, kk, lane);
+      }
+#pragma unroll
+      for (int b = 0; b < FB; ++b)
+#pragma unroll
+        for (int a = 0; a < FA; ++a)
+          acc[b][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b], xf[a], acc[b][a], 0, 0, 0);
+      if (XS && xs_on && t == xs_next) { VAC_XSUM_MFMA(xf) }
+    }
+    if (XS && xs_on && t == xs_next) xs_next += p.tiles_n;
+    // tile t+1 landed (this wave's loads; newer tiles may still fly), LDS reads of this slot retired; then everyone's
+    wait_vm_lgkm<LOADS * (NSTAGE - 2)>();
+    __builtin_amdgcn_s_barrier();
+    cur = cur + 1 == NSTAGE ? 0 : cur + 1;
+    nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
+  }
+  }
+#undef VAC_XSUM
+#undef VAC_XSUM_MFMA
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the (zero-fill) tail loads before LDS is reused
+  __builtin_amdgcn_s_barrier();
+
+  if (XS && xs_on && lane < 16) {
+    // C^T layout: lanes 0..15 hold result rows 0..3 (element j = row), column m = lane
+#pragma unroll
+    for (int i = 0; i < XSN; ++i) {
+      const int m = m0 + wm * TM + (wn * XSN + i) * 16 + lane;
+      if (m < p.M) atomicAdd(p.xsum + m, accs[i]);
+    }
+  }
+
+  // The epilogue reads its parameters through opaque copies: inside the persistent work loop everything derived from the
+  // kernel arguments and the thread index is loop-invariant, and hoisting it all (dozens of precomputed branch masks and
+  // per-lane addresses) ahead of the loop spilled the K loop's fragment addresses to scratch.
+  GemmP q = p;
+  VAC_OPAQUE_S(q.bias); VAC_OPAQUE_S(q.out); VAC_OPAQUE_S(q.preact); VAC_OPAQUE_S(q.dact_src); VAC_OPAQUE_S(q.residual);
+  VAC_OPAQUE_S(q.M); VAC_OPAQUE_S(q.N); VAC_OPAQUE_S(q.ldo); VAC_OPAQUE_S(q.act); VAC_OPAQUE_S(q.out_mode);
+  VAC_OPAQUE_S(q.split_k); VAC_OPAQUE_S(q.alpha); VAC_OPAQUE_S(q.debug);
+  int te = threadIdx.x;
+  asm volatile("" : "+v"(te));
+  const int wve = __builtin_amdgcn_readfirstlane(te >> 6);
+  const int le = te & 63, lme = le & 15, ln4e = (le >> 4) * 4;
+  const int wme = wve % WM, wne = wve / WM;
+  const int vnext = vb + (int)gridDim.x;                // persistent launch: the next work item of this workgroup
+  const bool more = vnext < total;
+  Work wnx = wk;
+  if (more) wnx = coords(vnext);
+  int pend_next = 0;
+  bool done = false, staged = false;                    // staged: the next tile's prologue loads have been issued
+  if (q.debug & 4) { if (acc[0][0][0] == 12345.678f) ((float*)q.out)[0] = 0.f; done = true; }
+  // ---- direct epilogue for the common plain case (bf16 out, bias + activation only): each le owns 4 consecutive n of
+  // one m per accumulator tile -> bias as one 16-byte load, pack with v_cvt_pk_bf16_f32, one 8-byte store.  No LDS
+  // round trip, no barriers; the 32-byte row pieces of the four n-groups are merged by the L2.
+  if (!done && BM <= 128 && q.out_mode == 0 && !q.preact && !q.dact_src && !q.residual && (q.ldo & 3) == 0 && !(q.debug & 16)) {
+    const bool add_bias_ = q.bias != nullptr;
+#pragma unroll
+    for (int a = 0; a < FA; ++a) {
+      const int m = m0 + wme * TM + a * 16 + lme;
+      if (m >= q.M) continue;
+      bf16_t* orow = (bf16_t*)q.out + (size_t)m * q.ldo;
+#pragma unroll
+      for (int b = 0; b < FB; ++b) {
+        const int n = n0 + wne * TN + b * 16 + ln4e;
+        if (n + 4 <= q.N) {
+          f32x4 v = acc[b][a];
+          if (q.alpha != 1.0f) v *= q.alpha;
+          if (add_bias_) v += *(const f32x4*)(q.bias + n);
+          if (q.act != VACNIC_ACT_NONE) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = act_fwd(q.act, v[j]);
+          }
+          *(u32x2*)(orow + n) = (u32x2){pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+        } else if (n < q.N) {
+          for (int j = 0; j < 4 && n + j < q.N; ++j) {
+            float v = acc[b][a][j] * q.alpha + (add_bias_ ? q.bias[n + j] : 0.f);
+            orow[n + j] = f2bf(act_fwd(q.act, v));
+          }
+        }
+      }
+    }
+    done = true;
+  }
+  // ---- bf16 epilogue of the 256-row tiles (bf16 output, 16-byte output rows): bias (+ activation when nothing else
+  // needs the pre-activation) on the fp32 accumulators in registers, round ONCE to bf16 and transpose the whole C tile
+  // through LDS in a single pass (BM x BN x 2 B <= 128 KiB, XOR-swizzled 16-byte chunks: conflict-free 8-byte writes
+  // from the C^T fragments, conflict-free 16-byte row reads), so that every global access is a 16-byte row-contiguous
+  // one.  One barrier pair per tile instead of four fp32 passes (2 us instead of 7.7 us per 256x256 tile).  Saved
+  // pre-activation, fused activation-backward and residual are applied on the bf16 value after the transposition — the
+  // arithmetic of a bf16 autocast Linear followed by a bf16 elementwise op.
+  if constexpr (BM == 256 && BN >= 128) {
+    if (!done && q.out_mode == 0 && (q.ldo & 7) == 0 && (q.N & 7) == 0 && !(q.debug & 16)) {
+      static_assert(BM * ROWB <= NSTAGE * STAGE, "bf16 C tile must fit in the operand ring");
+      const bool act_in_regs = q.act != VACNIC_ACT_NONE && !q.preact && !q.dact_src;
+      f32x4 bia[FB];
+#pragma unroll
+      for (int b = 0; b < FB; ++b) {
+        const int n = n0 + wne * TN + b * 16 + ln4e;
+        bia[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (q.bias) {
+          if (n + 4 <= q.N) bia[b] = *(const f32x4*)(q.bias + n);
+          else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (n + j < q.N) bia[b][j] = q.bias[n + j];
+          }
+        }
+      }
+      auto deposit = [&](auto act_c) {
+        constexpr int ACT = decltype(act_c)::value;
+#pragma unroll
+        for (int a = 0; a < FA; ++a) {
+          const int row = wme * TM + a * 16 + lme;
+          char* rp = smem + row * ROWB;
+#pragma unroll
+          for (int b = 0; b < FB; ++b) {
+            f32x4 v = acc[b][a];
+            if (q.alpha != 1.0f) v *= q.alpha;
+            v += bia[b];
+            if (ACT != VACNIC_ACT_NONE) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] = act_fwd(ACT, v[j]);
+            }
+            const int nl = wne * TN + b * 16 + ln4e;
+            *(u32x2*)(rp + ((((nl >> 3) ^ (row & 15)) << 4) | (((nl >> 2) & 1) << 3))) = (u32x2){pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+          }
+        }
+      };
+      const int act_regs = act_in_regs ? q.act : VACNIC_ACT_NONE;
+      if (act_regs == VACNIC_ACT_GELU) deposit(IC<VACNIC_ACT_GELU>{});
+      else if (act_regs == VACNIC_ACT_TANH) deposit(IC<VACNIC_ACT_TANH>{});
+      else if (act_regs == VACNIC_ACT_QUICKGELU) deposit(IC<VACNIC_ACT_QUICKGELU>{});
+      else deposit(IC<VACNIC_ACT_NONE>{});
+      lds_barrier();
+      static_assert(NTHR % NCH == 0 && BM % RSTEP == 0 && NIT % 8 == 0, "epilogue sweep mapping");
+      const int c = te % NCH, rb = te / NCH;
+      u32x4 cv[NIT];
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) {
+        const int row = rb + k * RSTEP;
+        cv[k] = *(const u32x4*)(smem + row * ROWB + ((c ^ (row & 15)) << 4));
+      }
+      if (more) {
+        // the C tile is in registers: the next tile's loads go out BEFORE this tile's stores (see `pend`)
+        lds_barrier();
+        prologue(wnx, wve, le);
+        staged = true;
+      }
+      // Global traffic of the epilogue through buffer instructions: rows >= M (and, with debug bit 0, everything) fall
+      // outside the descriptor's range — loads return 0, stores are dropped — so there is no branch around any access
+      // (a branch per load makes hipcc wait for each load separately) and every wave issues exactly NIT stores per output.
+      const unsigned span = (unsigned)((((size_t)q.M - 1) * q.ldo + q.N) * 2);
+      const int n = n0 + c * 8;
+      const unsigned rstride = (unsigned)(RSTEP * q.ldo * 2);
+      unsigned voff = (n + 8 <= q.N && !(q.debug & 1)) ? (unsigned)(((size_t)(m0 + rb) * q.ldo + n) * 2) : (unsigned)OOB;
+      const unsigned vstep = (n + 8 <= q.N && !(q.debug & 1)) ? rstride : 0u;
+      __amdgpu_buffer_rsrc_t so = __builtin_amdgcn_make_buffer_rsrc(q.out, 0, span, 0x00020000);
+      const bool plain = !q.preact && !q.dact_src && !q.residual;
+      // exactly one of residual / preact / dact_src may ride on this path (the host sends combinations to the fp32 path);
+      // each gets its own straight-line instance: MODE 1 residual, 2 saved pre-activation (+ activation), 3 activation backward
+      auto tail = [&](auto mode_c, auto act_c) {
+        constexpr int MODE = decltype(mode_c)::value, ACT = decltype(act_c)::value;
+        const void* eptr = MODE == 1 ? (const void*)q.residual : MODE == 2 ? (const void*)q.preact : (const void*)q.dact_src;
+        __amdgpu_buffer_rsrc_t se = __builtin_amdgcn_make_buffer_rsrc((void*)eptr, 0, span, 0x00020000);
+#pragma unroll
+        for (int k0 = 0; k0 < NIT; k0 += 8) {
+          u32x4 ex[8];
+          __builtin_amdgcn_sched_barrier(0);          // one batch of 8 rows at a time (the C tile already holds 64 registers)
+          if (MODE != 2) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ex[k] = __builtin_amdgcn_raw_buffer_load_b128(se, voff + (k0 + k) * vstep, 0, 0);
+          }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            float v[8], d[8];
+            unpack8bf(cv[k0 + k], v);
+            if (MODE == 2) {
+              __builtin_amdgcn_raw_buffer_store_b128(cv[k0 + k], se, voff + (k0 + k) * vstep, 0, 0);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] = act_fwd(ACT, v[j]);
+            } else {
+              unpack8bf(ex[k], d);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] = MODE == 1 ? v[j] + d[j] : v[j] * act_bwd(ACT, d[j]);
+            }
+            const u32x4 o = (u32x4){pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+            __builtin_amdgcn_raw_buffer_store_b128(o, so, voff + (k0 + k) * vstep, 0, 0);
+          }
+        }
+      };
+      if (plain) {
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) __builtin_amdgcn_raw_buffer_store_b128(cv[k], so, voff + k * vstep, 0, 0);
+        pend_next = NIT;
+      } else if (q.residual) {
+        tail(IC<1>{}, IC<VACNIC_ACT_NONE>{});
+        pend_next = NIT;
+      } else if (q.preact) {
+        if (q.act == VACNIC_ACT_GELU) tail(IC<2>{}, IC<VACNIC_ACT_GELU>{});
+        else if (q.act == VACNIC_ACT_TANH) tail(IC<2>{}, IC<VACNIC_ACT_TANH>{});
+        else if (q.act == VACNIC_ACT_QUICKGELU) tail(IC<2>{}, IC<VACNIC_ACT_QUICKGELU>{});
+        else tail(IC<2>{}, IC<VACNIC_ACT_NONE>{});
+        pend_next = 2 * NIT;
+      } else {
+        if (q.act == VACNIC_ACT_GELU) tail(IC<3>{}, IC<VACNIC_ACT_GELU>{});
+        else if (q.act == VACNIC_ACT_TANH) tail(IC<3>{}, IC<VACNIC_ACT_TANH>{});
+        else if (q.act == VACNIC_ACT_QUICKGELU) tail(IC<3>{}, IC<VACNIC_ACT_QUICKGELU>{});
+        else tail(IC<3>{}, IC<VACNIC_ACT_NONE>{});
+        pend_next = NIT;
+      }
+      done = true;
+    }
+  }
+  if (!done) {
+  // ---- fp32 epilogue (f32 / accumulating outputs, unaligned output rows, the small-tile configs with a fused
+  // pre-activation / activation-backward / residual): stage the fp32 C tile through LDS (the operand buffers are free
+  // now) in 64-row passes, then every thread handles 8 consecutive n of one row: 16-byte coalesced traffic for the
+  // output, the saved pre-activation, the activation-backward source and the residual.
+  float* sc = (float*)smem;                 // [64][CLD] f32
+  constexpr int CLD = BN + 4;
+  constexpr int PASSES = (BM + 63) / 64;
+  const bool vec_ok = (q.ldo & 7) == 0;
+  const bool add_bias = zsplit == 0;
+  float bia[8];
+  // A pass stages 64 tile rows: RPWM = 64/WM rows from EACH wve row-group, so that every wve deposits in every pass (the
+  // LDS store path has two halves, SIMDs {0,1} and {2,3}; a pass fed by the waves of one wme only ran it at half rate).
+  // LDS row r of pass p holds tile row (r / RPWM) * TM + p * RPWM + r % RPWM.
+  constexpr int RPWM = 64 / WM;
+  static_assert((RPWM % 16 == 0 && TM % RPWM == 0) || BM < 64, "epilogue pass mapping");
+  auto tile_row = [&](int pass, int r) { return (r / RPWM) * TM + pass * RPWM + r % RPWM; };
+#pragma unroll
+  for (int pass = 0; pass < PASSES; ++pass) {
+#pragma unroll
+    for (int a = 0; a < FA; ++a) {
+      if ((a * 16) / RPWM == pass) {
+#pragma unroll
+        for (int b = 0; b < FB; ++b)
+          *(f32x4*)(sc + (wme * RPWM + (a * 16) % RPWM + lme) * CLD + wne * TN + b * 16 + ln4e) = acc[b][a];
+      }
+    }
+    __syncthreads();
+    if (q.out_mode == 2 && q.split_k > 1) {
+      // split-K accumulate: f32 atomics shaped as 256 contiguous bytes per wve-instruction (one row, 64
+      // consecutive columns) — the shape the memory-side atomic units run at full rate on
+      constexpr int RPW = 64 / NWAVE;
+#pragma unroll 1
+      for (int rr = 0; rr < RPW; ++rr) {
+        const int row = wve * RPW + rr;
+        const int m = m0 + tile_row(pass, row);
+        if (m >= q.M) continue;
+#pragma unroll
+        for (int h = 0; h < BN / 64; ++h) {
+          const int n = n0 + h * 64 + le;
+          if (n < q.N) {
+            float v = sc[row * CLD + h * 64 + le] * q.alpha;
+            if (q.bias && add_bias) v += q.bias[n];
+            atomicAdd((float*)q.out + (size_t)m * q.ldo + n, v);
+          }
+        }
+      }
+      __syncthreads();
+      continue;
+    }
+    // every thread owns ONE 8-wide column group (NTHR is a multiple of the chunks per row) and RPT rows of the pass: the LDS
+    // reads and the residual / activation-source loads of all RPT chunks are issued before any of them is consumed, and the
+    // bias is loaded once per kernel — a chunk-at-a-time loop exposed one L2 round trip per chunk (7-9 us per tile).
+    constexpr int CPR = BN / 8;               // 8-wide chunks per row
+    constexpr int RPT = 64 * CPR / NTHR;      // chunks per thread per pass
+    constexpr int RSTEP = NTHR / CPR;
+    static_assert((64 * CPR) % NTHR == 0 && NTHR % CPR == 0, "epilogue chunk mapping");
+    const int c8 = (te % CPR) * 8, rbase = te / CPR;
+    const int n = n0 + c8;
+    const bool fast = vec_ok && n + 8 <= q.N && (q.out_mode == 0 || (q.ldo & 3) == 0);
+    if (fast) {
+      if (pass == 0) {
+        if (q.bias && add_bias) {
+          const f32x4 b0 = *(const f32x4*)(q.bias + n), b1 = *(const f32x4*)(q.bias + n + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { bia[j] = b0[j]; bia[4 + j] = b1[j]; }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bia[j] = 0.f;
+        }
+      }
+      float v[RPT][8];
+      u32x4 rraw[RPT], draw[RPT];
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        const int row = rbase + k * RSTEP;
+        const int m = m0 + tile_row(pass, row);
+        const f32x4 v0 = *(const f32x4*)(sc + row * CLD + c8), v1 = *(const f32x4*)(sc + row * CLD + c8 + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[k][j] = v0[j]; v[k][4 + j] = v1[j]; }
+        rraw[k] = (u32x4){0, 0, 0, 0}; draw[k] = (u32x4){0, 0, 0, 0};
+        if (m < q.M) {
+          const size_t off = (size_t)m * q.ldo + n;
+          if (q.residual) rraw[k] = *(const u32x4*)(q.residual + off);
+          if (q.dact_src) draw[k] = *(const u32x4*)(q.dact_src + off);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        const int m = m0 + tile_row(pass, rbase + k * RSTEP);
+        if (m < q.M) epilogue8_vec(q, v[k], (size_t)m * q.ldo + n, bia, rraw[k], draw[k]);
+      }
+    } else if (n < q.N) {
+#pragma unroll 1
+      for (int k = 0; k < RPT; ++k) {
+        const int row = rbase + k * RSTEP;
+        const int m = m0 + tile_row(pass, row);
+        if (m < q.M) {
+          float v[8];
+          const f32x4 v0 = *(const f32x4*)(sc + row * CLD + c8), v1 = *(const f32x4*)(sc + row * CLD + c8 + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { v[j] = v0[j]; v[4 + j] = v1[j]; }
+          epilogue8(q, v, m, n, add_bias, vec_ok);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  }   // fp32 epilogue
+  if (!more) break;
+  if (!staged) {
+    lds_barrier();                   // every LDS read of this tile's epilogue has retired
+    prologue(wnx, wve, le);
+  }
+  wk = wnx; vb = vnext; pend = pend_next;
+  }   // work loop
+}
+
+
+template <int BM, int BN, int WM, int WN, int BKT, int NSTAGE, bool PIPE = false>
+int launch_gemm(const GemmP& p0, bool xks, bool wks, int zsplits, hipStream_t s) {
+  GemmP p = p0;
+  p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
+  int nwg = p.tiles_m * p.tiles_n * zsplits;
+  if (PIPE && BKT == 32 && NSTAGE == 4 && !(p.debug & 64)) {
+    // persistent launch of the ping-pong configurations: one workgroup per CU walks the work items (gemm_kernel's work loop)
+    static int ncu = 0;
+    if (ncu == 0) {
+      int dev = 0; hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+      if (ncu <= 0) ncu = 256;
+      ncu = ncu / 8 * 8 > 0 ? ncu / 8 * 8 : 8;          // grid % 8 == 0 keeps a workgroup on one XCD's tile run
+    }
+    if (nwg > ncu) nwg = ncu;
+  }
+  dim3 grid(nwg), block(64 * WM * WN);
+  constexpr size_t lds = NSTAGE * (BM + BN) * BKT * 2;
+  static_assert(lds >= 64 * (BN + 4) * 4, "epilogue staging must fit in the operand buffers");
+#define VAC_LAUNCH(XK, WK)                                                                            \
+  do {                                                                                                \
+    auto kern = gemm_kernel<BM, BN, WM, WN, BKT, NSTAGE, PIPE, XK, WK>;                                                  \
+    if (lds > 65536) {                                                                                \
+      static bool once = false;                                                                       \
+      if (!once) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; } \
+    }                                                                                                 \
+    hipLaunchKernelGGL(kern, grid, block, lds, s, p);                                                 \
+  } while (0)
+  if (!xks && !wks) VAC_LAUNCH(false, false);
+  else if (!xks && wks) VAC_LAUNCH(false, true);
+  else if (xks && wks) VAC_LAUNCH(true, true);
+  else VAC_LAUNCH(true, false);
+#undef VAC_LAUNCH
+  VLAUNCH_CHECK();
+  return VACNIC_OK;
+}
+
+
+// one entry per tile configuration (defined in gemm_t*.hip)
+int launch_t256(const GemmP& p, bool xks, bool wks, int zsplits, hipStream_t s);   // 256x256 ping-pong
+int launch_t264(const GemmP& p, bool xks, bool wks, int zsplits, hipStream_t s);   // 256x128 ping-pong
+int launch_t128(const GemmP& p, bool xks, bool wks, int zsplits, hipStream_t s);   // 128x128 software-pipelined
+int launch_t64(const GemmP& p, bool xks, bool wks, int zsplits, hipStream_t s);    // 64x128, 4-deep ring
+int launch_t260(const GemmP& p, bool xks, bool wks, int zsplits, hipStream_t s);   // A/B baselines kept for the ablations in profiles/
+int launch_t261(const GemmP& p, bool xks, bool wks, int zsplits, hipStream_t s);
+int launch_t262(const GemmP& p, bool xks, bool wks, int zsplits, hipStream_t s);
+
+}  // namespace vacgemm

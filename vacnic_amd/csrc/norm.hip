@@ -126,6 +126,7 @@ __global__ __launch_bounds__(64 * NW) void add_ln_bwd_kernel(const bf16_t* __res
                                                          const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                          bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
                                                          float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                         float* __restrict__ partials,
                                                          int64_t R, int D, float p_drop, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -214,7 +215,11 @@ __global__ __launch_bounds__(64 * NW) void add_ln_bwd_kernel(const bf16_t* __res
             float t = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) t += red[w][e];
-            atomicAdd(dst + c * 8 + (e & 7), t);
+            // two-stage reduction: this block's column sums go to its own row of the scratch [gridDim.x][2][D] (plain
+            // 256-byte stores); ln_partial_reduce_kernel folds the rows into dgamma / dbeta.  With ~1000 blocks adding
+            // into the same 8 KiB the memory-side atomic units serialise (the kernel ran at 2.6 TB/s, its forward at 4.7).
+            if (partials) partials[((size_t)blockIdx.x * 2 + pass) * D + c * 8 + (e & 7)] = t;
+            else atomicAdd(dst + c * 8 + (e & 7), t);
           }
         }
       }
@@ -480,6 +485,37 @@ extern "C" int vacnic_add_ln_fwd(const vacnic_add_ln_fwd_args* a, void* stream) 
   return VACNIC_OK;
 }
 
+// partials [NB][2][D] -> dgamma[D] += sum_b partials[b][0][:], dbeta[D] += sum_b partials[b][1][:].
+// grid (2D/64, RS): block (cb, rs) owns 64 columns of the [.., 2D] view and every RS-th group of rows; its 4 waves take
+// interleaved rows (256 contiguous bytes per wave-load, 8 loads in flight), meet in LDS, one atomic per column per block.
+__global__ __launch_bounds__(256) void ln_partial_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dgamma,
+                                                                float* __restrict__ dbeta, int NB, int D) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;                 // column of the [NB][2D] view
+  const int RS = gridDim.y;
+  float t = 0.f;
+  if (col < 2 * D) {
+    int b = blockIdx.y * 4 + wave;
+    const int step = RS * 4;
+    for (; b + 7 * step < NB; b += 8 * step) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = partials[(size_t)(b + u * step) * 2 * D + col];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t += v[u];
+    }
+    for (; b < NB; b += step) t += partials[(size_t)b * 2 * D + col];
+  }
+  __shared__ float red[4][64];
+  red[wave][lane] = t;
+  __syncthreads();
+  if (wave == 0 && col < 2 * D) {
+    t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    float* dst = col < D ? dgamma + col : dbeta + (col - D);
+    if (col < D ? dgamma != nullptr : dbeta != nullptr) atomicAdd(dst, t);
+  }
+}
+
 extern "C" int vacnic_add_ln_bwd(const vacnic_add_ln_bwd_args* a, void* stream) {
   VCHECK(a && a->dout && a->x && a->gamma && a->mean && a->rstd, VACNIC_BAD_SHAPE, "add_ln_bwd: null operand");
   if (int e = check_d(a->D, "add_ln_bwd")) return e;
@@ -488,7 +524,7 @@ extern "C" int vacnic_add_ln_bwd(const vacnic_add_ln_bwd_args* a, void* stream) 
 #define LAUNCH_LN_BWD(NCH_, NW_, NB_)                                                                                  \
   hipLaunchKernelGGL((add_ln_bwd_kernel<NCH_, NW_>), dim3((unsigned)(NB_)), dim3(64 * NW_), 0, st, (const bf16_t*)a->dout, \
                      (const bf16_t*)a->x, (const bf16_t*)a->residual, a->gamma, a->mean, a->rstd, (bf16_t*)a->dresidual, \
-                     (bf16_t*)a->dx, a->dgamma, a->dbeta, a->R, (int)a->D, a->p_drop, a->seed, a->seed_dev)
+                     (bf16_t*)a->dx, a->dgamma, a->dbeta, part, a->R, (int)a->D, a->p_drop, a->seed, a->seed_dev)
   const int nch = nch_for(a->D);
   // 4-wave blocks (<= 1024 of them).  16-wave blocks cut the same-address dgamma/dbeta atomics 4x and are 5 us faster when the
   // kernel runs alone, but a 1024-thread block needs a completely free CU: beside the weight-gradient stream's GEMMs the
@@ -496,11 +532,18 @@ extern "C" int vacnic_add_ln_bwd(const vacnic_add_ln_bwd_args* a, void* stream) 
   {
     int64_t nb = (a->R + 3) / 4;
     if (nb > 1024) nb = 1024;
+    // two-stage dgamma/dbeta when the caller lends a scratch of >= nb rows and the atomics would collide (many blocks)
+    float* part = (a->partials && a->partial_rows >= nb && nb >= 64 && (a->dgamma || a->dbeta)) ? a->partials : nullptr;
     switch (nch) {
       case 1: LAUNCH_LN_BWD(1, 4, nb); break;
       case 2: LAUNCH_LN_BWD(2, 4, nb); break;
       case 3: LAUNCH_LN_BWD(3, 4, nb); break;
       default: LAUNCH_LN_BWD(4, 4, nb); break;
+    }
+    if (part) {
+      VLAUNCH_CHECK();
+      hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3((unsigned)((2 * a->D + 63) / 64), 8), dim3(256), 0, st, part, a->dgamma,
+                         a->dbeta, (int)nb, (int)a->D);
     }
   }
 #undef LAUNCH_LN_BWD

@@ -83,7 +83,7 @@ _load_tuned()
 
 
 def gemm(x, w, M, N, K, *, bias=None, out=None, ldx=None, ldw=None, ldo=None, x_kstrided=False, w_kstrided=False,
-         act=None, out_mode=0, split_k=1, alpha=1.0, preact=None, dact_src=None, residual=None, tile_hint=0):
+         act=None, out_mode=0, split_k=1, alpha=1.0, preact=None, dact_src=None, residual=None, tile_hint=0, xsum=None):
     """out[m][n] = epi(alpha * sum_k X(m,k) W(n,k) + bias[n]) — see include/vacnic_hip.h.
     tile_hint 0: measured winner for this exact shape if gemm_tuned.json has one, else the C-side cost model; -1: cost model."""
     if out is None:
@@ -103,7 +103,7 @@ def gemm(x, w, M, N, K, *, bias=None, out=None, ldx=None, ldw=None, ldo=None, x_
     if tile_hint < 0:
         tile_hint = 0
     call_struct("vacnic_gemm_bf16", stream=_stream(), x=_p(x), w=_p(w), bias=_p(bias), out=_p(out), preact=_p(preact),
-                dact_src=_p(dact_src), residual=_p(residual), M=M, N=N, K=K, ldx=ldx, ldw=ldw, ldo=ldo,
+                dact_src=_p(dact_src), residual=_p(residual), xsum=_p(xsum), M=M, N=N, K=K, ldx=ldx, ldw=ldw, ldo=ldo,
                 x_kstrided=int(x_kstrided), w_kstrided=int(w_kstrided), act=ACT[act], out_mode=out_mode,
                 split_k=split_k, alpha=alpha, tile_hint=tile_hint)
     return out
@@ -141,6 +141,8 @@ def attn_bwd(q, k, v, out, dout, lse, dq, dk, dv, B, H, Tq, Tk, key_mask=None, c
 
 
 # -------------------------------------------------------------------------------------------- LN family
+LN_TWO_STAGE = __import__("os").environ.get("VACNIC_LN_ATOMICS") != "1"     # A/B: VACNIC_LN_ATOMICS=1 = round-1 per-column atomics
+
 def add_ln_fwd(x, residual, gamma, beta, eps=1e-5, p_drop=0.0, seed=0, need_stats=True, seed_dev=None):
     D = x.shape[-1]
     R = x.numel() // D
@@ -162,9 +164,13 @@ def add_ln_bwd(dout, x, residual, gamma, mean, rstd, dgamma, dbeta, p_drop=0.0, 
         dres = torch.empty_like(x)
     else:
         dres = None            # identical to dx: caller reuses dx
+    part, prow = None, 0
+    if LN_TWO_STAGE and dgamma is not None and R >= 256:
+        prow = min(1024, (R + 3) // 4)
+        part = torch.empty((prow, 2, D), device=x.device, dtype=torch.float32)     # scratch of the two-stage dgamma/dbeta fold
     call_struct("vacnic_add_ln_bwd", stream=_stream(), dout=_p(dout), x=_p(x), residual=_p(residual), gamma=_p(gamma),
                 mean=_p(mean), rstd=_p(rstd), dresidual=_p(dres), dx=_p(dx), dgamma=_p(dgamma), dbeta=_p(dbeta),
-                R=R, D=D, p_drop=p_drop, seed=seed, seed_dev=_p(seed_dev))
+                R=R, D=D, p_drop=p_drop, seed=seed, seed_dev=_p(seed_dev), partials=_p(part), partial_rows=prow)
     return dx, (dres if dres is not None else dx)
 
 

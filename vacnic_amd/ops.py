@@ -19,6 +19,7 @@ from . import kernels as K
 from . import streams
 
 BF16 = torch.bfloat16
+_NO_XSUM = __import__("os").environ.get("VACNIC_NO_XSUM") == "1"
 
 
 class Rng:
@@ -80,13 +81,20 @@ def _wgrad(dy2d, x2d, spec, M):
 
 
 def _wgrad_impl(dy2d, x2d, spec, M):
-    if spec.wgrad is not None:
+    if spec.wgrad is not None and not _NO_XSUM:
         N, Kd = spec.N, spec.K
         tiles = ((N + 127) // 128) * ((Kd + 127) // 128)
+        # the bias gradient (column sums of dY) rides on the weight-gradient GEMM's own dY fragments (xsum): no second pass
         K.gemm(dy2d, x2d, N, Kd, M, out=spec.wgrad, ldx=dy2d.stride(0), ldw=x2d.stride(0), ldo=spec.wgrad.stride(0),
-               x_kstrided=True, w_kstrided=True, out_mode=2, split_k=K.wgrad_split(M, tiles))
-    if spec.bgrad is not None:
-        K.bias_grad(dy2d, spec.bgrad, M, spec.N)
+               x_kstrided=True, w_kstrided=True, out_mode=2, split_k=K.wgrad_split(M, tiles), xsum=spec.bgrad)
+    else:
+        if spec.wgrad is not None:                  # A/B: VACNIC_NO_XSUM=1 restores the separate bias-gradient reduction
+            N, Kd = spec.N, spec.K
+            tiles = ((N + 127) // 128) * ((Kd + 127) // 128)
+            K.gemm(dy2d, x2d, N, Kd, M, out=spec.wgrad, ldx=dy2d.stride(0), ldw=x2d.stride(0), ldo=spec.wgrad.stride(0),
+                   x_kstrided=True, w_kstrided=True, out_mode=2, split_k=K.wgrad_split(M, tiles))
+        if spec.bgrad is not None:
+            K.bias_grad(dy2d, spec.bgrad, M, spec.N)
 
 
 # ------------------------------------------------------------------------------------------- Linear
