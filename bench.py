@@ -43,7 +43,8 @@ def parse():
     ap.add_argument("--seq", type=int, default=512, help="article tokens S")
     ap.add_argument("--cap", type=int, default=64, help="caption tokens T")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=1)
+    ap.add_argument("--cpu-batch", type=int, default=2, help="batch of the CPU baseline legs (SURVEY §8d: 2)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the target-GEMM and config-5 (caption generation) legs")
     ap.add_argument("--grad-transport", choices=("fp32", "bf16"), default="fp32",
                     help="N>1: dtype of the gradient all-reduce (fp32 = the reference's DDP; bf16 halves the xGMI volume)")
     ap.add_argument("--no-streams", action="store_true", help="single-stream schedule (no side streams for guide / wgrad)")
@@ -94,18 +95,27 @@ class GemmTimer:
         return agg
 
 
-def cpu_baseline(cfg, vcfg, B, S, T):
-    """The oracle (CPU restatement, torch fp32 + autograd) timed on this box's host cores: fwd + bwd + AdamW of the
-    same step at the same shapes, reduced batch.  Reported beside the GPU number, never the target."""
-    from oracle import vacnic_oracle as O
-    from vacnic_amd import synthetic
+def _cpu_info():
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    cores = min(cores, 16)                      # the box's CPU share for one GPU; more threads only thrash
-    torch.set_num_threads(cores)
+    model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    return cores, model
+
+
+def _cpu_leg(cfg, vcfg, B, S, T, threads, timed=3):
+    """one configuration of the CPU baseline: the oracle's full train step (fwd + bwd + AdamW), 1 warm-up + best of `timed`."""
+    from oracle import vacnic_oracle as O
+    from vacnic_amd import synthetic
     pool = torch.randn(1 << 24, generator=torch.Generator().manual_seed(0)) * 0.02
 
     def rand_sd(shapes):
@@ -121,11 +131,11 @@ def cpu_baseline(cfg, vcfg, B, S, T):
                 out[k] = torch.ones(v) if k.endswith("weight") else torch.zeros(v)
         return out
     sd = rand_sd(synthetic.mmbart_param_shapes(cfg))
-    sd_g = rand_sd(synthetic.guide_bart_param_shapes(cfg))
+    sd_g = None if cfg.only_image else rand_sd(synthetic.guide_bart_param_shapes(cfg))
     sd_c = rand_sd(synthetic.clip_visual_param_shapes(vcfg))
     for v in sd.values():
         v.requires_grad_(True)
-    batch = synthetic.make_batch(cfg, B, S=S, T=T, seed=1, full_length=True)
+    batch = synthetic.make_batch(cfg, B, S=S, T=T, seed=1, full_length=True, image_size=vcfg.image_size)
     m = {k: torch.zeros_like(v) for k, v in sd.items()}
     vv = {k: torch.zeros_like(v) for k, v in sd.items()}
 
@@ -138,24 +148,118 @@ def cpu_baseline(cfg, vcfg, B, S, T):
                     continue
                 np_, m[k], vv[k] = O.adamw_step(p, p.grad, m[k], vv[k], i + 1, 3e-5)
                 p.copy_(np_); p.grad = None
-    log("  oracle weights ready; warm-up step")
     step(0)                                     # warm-up
     best = 1e30
-    for i in range(1):
-        t0 = time.time(); step(i + 1); best = min(best, time.time() - t0)
-        log(f"  oracle step {i}: {time.time() - t0:.1f}s")
-    return {"value": round(B / best, 4), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (torch fp32 CPU, {cores} threads) full train step fwd+bwd+AdamW, same model/shapes, batch {B} "
-                      f"(S={S}, T={T}), 1 timed step after 1 warm-up"}
+    for i in range(timed):
+        t0 = time.time(); step(i + 1); dt = time.time() - t0
+        best = min(best, dt)
+        log(f"  oracle step {i}: {dt:.1f}s")
+    return B / best
+
+
+def cpu_baseline(B, S, T):
+    """the oracle (CPU restatement, torch fp32 + autograd) timed on this box's host cores — cfg1 (BART-base +
+    ViT-B/32 only-image, the reference's CPU-runnable plumbing case) and cfg2 (the benchmarked model), batch 2, one warm-up
+    and the best of 3 timed steps each.  Reported beside the GPU number, never the target."""
+    from vacnic_amd.config import bart_base_vit_b32, bart_large_vit_l14
+    cores, cpu_model = _cpu_info()
+    threads = min(cores, 16)                     # the box's CPU share for one GPU; more threads only thrash
+    torch.set_num_threads(threads)
+    cfg1, vcfg1 = bart_base_vit_b32()
+    log("  cfg1 (BART-base + ViT-B/32 only-image)")
+    v1 = _cpu_leg(cfg1, vcfg1, B, S, T, threads)
+    cfg2, vcfg2 = bart_large_vit_l14()
+    log("  cfg2 (BART-large + ViT-L/14 full VACNIC)")
+    v2 = _cpu_leg(cfg2, vcfg2, B, S, T, threads)
+    return {"value": round(v2, 4), "unit": "samples/s", "cores": threads, "kind": "port", "cpu_model": cpu_model, "host_cores_visible": cores,
+            "sample": f"oracle (torch fp32 CPU, {threads} threads) full train step fwd+bwd+AdamW of configs[1] (BART-large + ViT-L/14 full "
+                      f"VACNIC), batch {B} (S={S}, T={T}), best of 3 timed steps after 1 warm-up",
+            "cfg1": {"value": round(v1, 4), "unit": "samples/s",
+                     "sample": f"same protocol, configs[0] (BART-base + ViT-B/32 --only_image), batch {B} (S={S}, T={T})"}}
+
+
+def target_gemm_leg():
+    """BASELINE target: the BART cross-attention K/V (and q / out) projection GEMM, M = B*S = 16384, N = K = 1024, alone on the
+    GPU with HIP events on its launch stream; also the batched form the decoder actually launches (N = 12 layers x 2048)."""
+    from vacnic_amd import kernels as K
+    out = {}
+    for name, M, N, Kd in (("M16384_N1024_K1024", 16384, 1024, 1024), ("M16384_N24576_K1024_batched_decoder_kv", 16384, 24576, 1024)):
+        x = (torch.randn(M, Kd, device="cuda") * 0.5).bfloat16()
+        w = (torch.randn(N, Kd, device="cuda") * 0.5).bfloat16()
+        b = torch.randn(N, device="cuda")
+        o = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        for _ in range(5):
+            K.gemm(x, w, M, N, Kd, bias=b, out=o)
+        best = 1e30
+        for _ in range(5):
+            s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(20):
+                K.gemm(x, w, M, N, Kd, bias=b, out=o)
+            e.record(); torch.cuda.synchronize()
+            best = min(best, s.elapsed_time(e) / 20 * 1e-3)
+        tf = 2.0 * M * N * Kd / best / 1e12
+        out[name] = {"us": round(best * 1e6, 2), "TFLOP/s": round(tf, 1), "frac": round(tf / PEAK_BF16_TFLOPS, 4)}
+        del x, w, o
+    return out
+
+
+def decode_leg(model, cfg, n=4):
+    """BASELINE configs[4]: captions/sec at batch 1, beam 5, max_length 50, length_penalty 2.0 (seed 42 inputs), on the model the
+    step just trained (eval mode, no guide needed).  min_length 49 forces full-length captions (random-init weights would emit
+    EOS at once): the worst case."""
+    from vacnic_amd import kernels as K, synthetic
+    from vacnic_amd.models.clip_vit import extract_clip_img_feat
+    from vacnic_amd.training import to_device
+    from vacnic_amd import streams
+    streams.enable(False)
+    model.eval()
+    times, tokens = [], 0
+    with torch.no_grad():
+        for i in range(n + 2):
+            b = to_device(synthetic.make_batch(cfg, 1, S=512, T=64, seed=42, step=i, full_length=True), "cuda")
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            mask, _ = K.prep_ids(b["article_ids"], 1)
+            nmask, _ = K.prep_ids(b["names_art_ids"], 1)
+            _, cls = extract_clip_img_feat(model.clip_model, b["img_tensor"])
+            out = model.generate(input_ids=b["article_ids"], attention_mask=mask, num_beams=5, max_length=50, length_penalty=2.0,
+                                 min_length=49, image_features=cls, face_features=b["face_emb"], face_mask=K.face_mask(b["face_emb"]),
+                                 name_ids=b["names_art_ids"], name_mask=nmask, add_ner_ffn=True)
+            torch.cuda.synchronize()
+            if i >= 2:
+                times.append(time.perf_counter() - t0)
+            tokens = int(out.shape[1])
+    model.train()
+    t = sum(times) / len(times)
+    return {"metric": "captions/sec, batch 1, beam 5, max_length 50, length_penalty 2.0 (BASELINE configs[4])", "value": round(1.0 / t, 2),
+            "unit": "captions/s", "ms_per_caption": round(t * 1e3, 1), "tokens": tokens, "n": len(times), "includes": "ViT + encoder + beam search"}
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher: start one process per GPU through torch.distributed.run as a CHILD
+    (this process has made no GPU call yet and never will), pass its output through and exit with its code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"--gpus {a.gpus} without WORLD_SIZE: launching {a.gpus} ranks via torch.distributed.run (port {port})")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus > 1 and world == 1:
-        raise SystemExit("launch with torch.distributed.run for --gpus > 1 (one process per GPU)")
+    if a.gpus != world:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch one process per GPU")
     # VACNIC_DIST_BACKEND=gloo VACNIC_SINGLE_DEVICE=1: rehearse the N>1 code path (tracker, bucket launches, side streams,
     # joins) with several ranks sharing ONE GPU — RCCL itself needs one GPU per rank, which only the driver's node has
     single_dev = os.environ.get("VACNIC_SINGLE_DEVICE") == "1"
@@ -246,8 +350,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    per_rank_ms = [round(dt / a.steps * 1e3, 2)]
     if world > 1:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        per_rank_ms = [round(v.item() / a.steps * 1e3, 2) for v in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     losses = out4.tolist()
@@ -289,14 +397,23 @@ def main():
                "launch_mode": ("hipGraph replay (K-1 steps) + 1 eager instrumented step" if graphed is not None else
                                "eager multi-stream" + (", frozen towers as hipGraph replays" if towers is not None else "")),
                "host_enqueue_ms_per_step": round(host_dt / a.steps * 1e3, 2),
+               "per_rank_ms_per_step": per_rank_ms,
+               "world_size_reported": dist.get_world_size() if world > 1 else 1,
+               "dist_backend": (backend if world > 1 else None), "grad_transport": (a.grad_transport if world > 1 else None),
                "step_tflops_per_gpu": round(value / world * gf / 1e3, 1) if gf else None,
                "step_mfma_frac": round(value / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4) if gf else None,
                "losses_last_step": {"total": losses[0], "txt": losses[1], "secla": losses[2], "colam": losses[3]},
                "roofline": roof}
+        if world == 1 and not a.no_extras:
+            try:
+                res["target_gemm"] = target_gemm_leg()
+                res["extra"] = {"config5_generation": decode_leg(model, cfg)}
+            except Exception as e:      # the extras must never sink the main measurement
+                res["extra"] = {"error": repr(e)}
         if world == 1 and not a.no_cpu_baseline:
             try:
                 log("cpu baseline (oracle on host cores)")
-                res["cpu_baseline"] = cpu_baseline(cfg, vcfg, a.cpu_batch, S, T)
+                res["cpu_baseline"] = cpu_baseline(a.cpu_batch, S, T)
                 log("cpu baseline done")
             except Exception as e:      # the baseline must never sink the GPU measurement
                 res["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}

@@ -375,7 +375,8 @@ def banned_ngram_tokens(seq, n):
 
 
 def beam_search_bookkeeping(step_logprobs_fn, B, num_beams, max_length, eos, pad, start, length_penalty=1.0,
-                            early_stopping=False, no_repeat_ngram_size=0, min_length=0, forced_eos_token_id=None, norm="v4.18"):
+                            early_stopping=False, no_repeat_ngram_size=0, min_length=0, forced_eos_token_id=None, norm="v4.18",
+                            forced_bos_token_id=None):
     """GenerationMixin.beam_search + BeamSearchScorer.process/finalize of transformers 4.18, driven by a callback
     `step_logprobs_fn(seqs) -> [B*num_beams, V]` log-softmax of the next-token logits for the current beams."""
     seqs = [[start] for _ in range(B * num_beams)]
@@ -393,6 +394,8 @@ def beam_search_bookkeeping(step_logprobs_fn, B, num_beams, max_length, eos, pad
                 lp[r, tok] = -float("inf")
             if cur_len < min_length:
                 lp[r, eos] = -float("inf")
+            if forced_bos_token_id is not None and cur_len == 1:             # ForcedBOSTokenLogitsProcessor
+                lp[r] = -float("inf"); lp[r, forced_bos_token_id] = 0.0
             if forced_eos_token_id is not None and cur_len == max_length - 1:
                 keep = lp[r, forced_eos_token_id].clone()
                 lp[r] = -float("inf"); lp[r, forced_eos_token_id] = 0.0 if keep == keep else 0.0
@@ -443,7 +446,8 @@ def beam_search_bookkeeping(step_logprobs_fn, B, num_beams, max_length, eos, pad
 
 def beam_search_decode(sd, cfg, input_ids, attention_mask, image_features, num_beams, max_length, length_penalty=1.0, **kw):
     """Cache-less beam search over the oracle model (config 5: beam 5, max_length 50, length_penalty 2.0)."""
-    gen = {k: kw.pop(k) for k in ("early_stopping", "no_repeat_ngram_size", "min_length", "forced_eos_token_id", "norm") if k in kw}
+    gen = {k: kw.pop(k) for k in ("early_stopping", "no_repeat_ngram_size", "min_length", "forced_eos_token_id", "norm",
+                                  "forced_bos_token_id") if k in kw}
     B = input_ids.shape[0]
     enc_h, _, _, _ = encoder(sd, cfg, input_ids, attention_mask, image_features, kw.get("name_ids"), kw.get("name_mask"),
                              kw.get("face_features"), kw.get("face_mask"))

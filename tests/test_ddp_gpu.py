@@ -1,0 +1,136 @@
+"""MI355X, world_size 2 on ONE GPU over gloo: the data-parallel reducer driven by the real HIP training step — tracker,
+bucket launches on the comm stream while backward is still running, waits on the weight-gradient / branch streams, SUM
+all-reduce, fp32 and bf16 transport — and the SURVEY §8d / §8e gate: N ranks x B samples must equal one rank evaluated
+per B-sample shard and averaged (SECLA keeps per-rank negatives, TRAIN:326-330), and for the sample-separable terms
+(CE with equal token counts, CoLaM) also one rank on the concatenated 2B batch.
+
+RCCL itself needs one GPU per rank (the driver's 8-GPU node); everything above the collective call is exercised here."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+B, S, T, F = 3, 48, 12, 3
+
+
+def _cfgs():
+    from vacnic_amd.config import ClipVisionConfig, VacnicConfig
+    cfg = VacnicConfig(d_model=768, encoder_layers=2, decoder_layers=2, encoder_attention_heads=12, decoder_attention_heads=12,
+                       encoder_ffn_dim=3072, decoder_ffn_dim=3072, enc_fusion_layer=[0], dim_common=768, clip_width=128, dropout=0.0)
+    vcfg = ClipVisionConfig(width=128, layers=1, patch_size=16, image_size=32, output_dim=64)
+    return cfg, vcfg
+
+
+def _batch(cfg, lo, hi):
+    """samples [lo, hi) of the global batch of 2B samples (full-length captions: equal CE token counts per shard)."""
+    from vacnic_amd import synthetic
+    full = synthetic.make_batch(cfg, 2 * B, S=S, T=T, F=F, seed=11, image_size=32, full_length=True)
+    return {k: v[lo:hi].contiguous().cuda() for k, v in full.items()}
+
+
+def _fwd_bwd(model, guide, batch, args):
+    from vacnic_amd import streams
+    from vacnic_amd.ddp import DistributedDataParallel
+    from vacnic_amd.training import forward_losses
+    net = model.module if isinstance(model, DistributedDataParallel) else model
+    net.arena.grad.zero_()
+    total, out4, _ = forward_losses(model, guide, batch, args)
+    with torch.autograd.set_multithreading_enabled(False):
+        total.backward()
+    streams.join_all()
+    if isinstance(model, DistributedDataParallel):
+        model.reduce_gradients()
+    torch.cuda.synchronize()
+    return out4.tolist(), net.arena.grad.clone()
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    try:
+        torch.cuda.set_device(0)
+        from vacnic_amd import ddp, streams
+        from vacnic_amd.training import TrainArgs, build_models
+        streams.enable(True)                                   # wgrad / branch side streams: the reducer must wait for them
+        cfg, vcfg = _cfgs()
+        model, guide, _ = build_models(cfg, vcfg, init="synthetic", seed=3)   # frozen guide / ViT: same "pretrained" weights on all ranks
+        if rank != 0:                                          # the trainable network starts DIFFERENT: the ctor broadcast must fix it
+            model.arena.flat32.mul_(1.0 + 0.01 * rank)
+            model.arena.refresh_shadow()
+        model.train()
+        args = TrainArgs()
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        res, kept = {}, {}
+        for transport in ("fp32", "bf16"):
+            w = ddp.DistributedDataParallel(model, bucket_bytes=8 << 20, grad_transport=transport)
+            assert ddp.TRACKER is w.tracker and len(w.tracker.buckets) > 8
+            launched_in_backward = []
+            orig = w._launch_bucket
+
+            def spy(start, orig=orig, log=launched_in_backward):       # tracker callback = a bucket completed DURING backward
+                log.append(start)
+                orig(start)
+            w.tracker.on_ready = spy
+            losses, gsum = _fwd_bwd(w, guide, _batch(cfg, rank * B, (rank + 1) * B), args)
+            assert len(launched_in_backward) >= len(w.tracker.buckets) // 2, "buckets must launch while backward is running"
+            gavg = gsum / world
+            res[transport] = {"losses": losses, "probe": gavg[::9973].double().cpu(), "norm": gavg.double().norm().item()}
+            kept[transport] = gavg
+            ddp.TRACKER = None
+        # the single-process references, computed by rank 0 with the (broadcast) rank-0 weights and no reducer
+        if rank == 0:
+            shard = [_fwd_bwd(model, guide, _batch(cfg, s * B, (s + 1) * B), args) for s in range(world)]
+            whole = _fwd_bwd(model, guide, _batch(cfg, 0, world * B), args)
+            g_ref = sum(g for _, g in shard) / world               # mean over shards of the per-shard gradient
+            res["shard_losses"] = [l for l, _ in shard]
+            res["whole_losses"] = whole[0]
+            res["ref_probe"] = g_ref[::9973].double().cpu()
+            for transport, g in kept.items():
+                res[transport]["rel_vs_shard_mean"] = ((g - g_ref).double().norm() / g_ref.double().norm()).item()
+        q.put((rank, "ok", res))
+    except Exception:
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc(), None))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_two_ranks_match_one_rank_per_shard_and_on_the_concatenated_batch():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    assert all(r[1] == "ok" for r in res), [r[1] for r in res]
+    by_rank = {r[0]: r[2] for r in res}
+    ref = by_rank[0]
+    for transport, tol in (("fp32", 1e-3), ("bf16", 6e-3)):           # bf16 transport rounds every bucket twice (2^-9 each)
+        for r in (0, 1):
+            # every loss term of rank r equals the single-process evaluation of shard r (total, txt, secla, colam)
+            for got, want in zip(by_rank[r][transport]["losses"], ref["shard_losses"][r]):
+                assert abs(got - want) <= 1e-3 * abs(want), (transport, r, by_rank[r][transport]["losses"], ref["shard_losses"][r])
+        # averaged gradient of the 2-rank step == mean over shards of the single-process gradient
+        assert ref[transport]["rel_vs_shard_mean"] <= tol, (transport, ref[transport]["rel_vs_shard_mean"])
+        # both ranks hold the same reduced gradient (probe of every 9973rd element + norm)
+        assert torch.equal(by_rank[0][transport]["probe"], by_rank[1][transport]["probe"]), transport
+        assert by_rank[0][transport]["norm"] == by_rank[1][transport]["norm"], transport
+    # concatenated batch on one rank: CE (equal token counts per shard) and CoLaM are sample means -> equal to the shard mean;
+    # SECLA is NOT (in-batch negatives are per rank by design, TRAIN:326-330): the N-rank value is the per-shard mean
+    whole = ref["whole_losses"]
+    mean_shard = [sum(l[i] for l in ref["shard_losses"]) / 2.0 for i in range(4)]
+    assert abs(whole[1] - mean_shard[1]) <= 1e-3 * abs(mean_shard[1]), ("txt", whole, mean_shard)
+    assert abs(whole[3] - mean_shard[3]) <= 1e-3 * abs(mean_shard[3]) + 1e-5, ("colam", whole, mean_shard)
+    ddp_secla = (by_rank[0]["fp32"]["losses"][2] + by_rank[1]["fp32"]["losses"][2]) / 2.0
+    assert abs(ddp_secla - mean_shard[2]) <= 1e-3 * abs(mean_shard[2]), ("secla per-shard mean", ddp_secla, mean_shard[2])

@@ -195,6 +195,21 @@ def test_checkpoint_round_trip_reference_names_on_host():
         assert torch.equal(o1.arena.exp_avg[o:o + n], o2.arena.exp_avg[o2_:o2_ + n])
         assert torch.equal(o1.arena.exp_avg_sq[o:o + n], o2.arena.exp_avg_sq[o2_:o2_ + n])
     assert torch.equal(o2.hyper, o1.hyper) and ops.Rng.base == 99 and ops.Rng.counter == 1234
+    # data-parallel resume: the checkpoint keeps the rank-free seed; rank r re-derives seed + r, so replicas keep distinct masks
+    assert ck["rng"]["seed"] == 99 and "base" not in ck["rng"]
+    bases = []
+    for r in (0, 1, 3):
+        ops.Rng.manual_seed(0)
+        checkpoint.load_checkpoint(ck, m2, o2, rank=r)
+        bases.append(ops.Rng.base)
+        assert ops.Rng.counter == 1234
+    assert bases == [99, 100, 102], bases
+    ops.Rng.manual_seed(41 + 2)                                               # saved BY rank 2 of a run seeded 41
+    ck2 = checkpoint.save_checkpoint(io.BytesIO(), m1, o1, step=1, rank=2)
+    assert ck2["rng"]["seed"] == 41
+    legacy = dict(ck, rng={"base": 7, "counter": 5, "device_counter": 0})     # format written before the per-rank fix
+    checkpoint.load_checkpoint(legacy, m2, o2, rank=1)
+    assert ops.Rng.base == 8 and ops.Rng.counter == 5
     with pytest.raises(KeyError):
         bad = dict(ck, model={k: v for k, v in ck["model"].items() if k != "lm_head.weight"})
         checkpoint.load_checkpoint(bad, m2, o2)

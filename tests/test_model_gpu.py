@@ -365,7 +365,9 @@ def test_greedy_decode_ids_match_oracle():
 
 
 GEN_CASES = [(5, 2.0, {}), (5, 1.0, {}), (1, 1.0, dict(min_length=4)), (5, 1.0, dict(min_length=4)),
-             (4, 2.0, dict(min_length=3, no_repeat_ngram_size=2)), (3, 0.5, dict(min_length=5, no_repeat_ngram_size=3, early_stopping=True))]
+             (4, 2.0, dict(min_length=3, no_repeat_ngram_size=2)), (3, 0.5, dict(min_length=5, no_repeat_ngram_size=3, early_stopping=True)),
+             # the generation defaults of the facebook/bart-* hub checkpoints (config.HUB_GENERATION_DEFAULTS) at config 5's beam / length penalty
+             (5, 2.0, dict(no_repeat_ngram_size=3, early_stopping=True, forced_bos_token_id=0))]
 
 
 def test_beam_search_kv_cache_matches_oracle_and_reference_golden():
@@ -497,6 +499,61 @@ def test_cfg4_long_article_1024_tokens_step_and_oracle():
     hist = [train_step(model, guide, opt, b4, TrainArgs(num_training_steps=100)).tolist() for _ in range(4)]
     assert all(np.isfinite(h).all() for h in hist), hist
     assert hist[-1][1] < hist[0][1], hist
+
+
+def test_cfg2_full_depth_matches_oracle_losses_states_and_gradients():
+    """BASELINE configs[1] at FULL depth and width — BART-large 12+12 layers, d=1024, CLIP ViT-L/14 (24 layers), full VACNIC
+    (clipcap prompt, SECLA, CoLaM a=0.5 m=1.0), 512-token articles, 64-token captions, dropout 0 — at batch 2, where the CPU
+    oracle's forward + backward takes seconds: bf16 through 24 residual layers against the fp32 restatement (SURVEY §7 hard
+    part (b)).  All four loss terms <= 1e-2 relative, the face / decoder states <= 2e-2 relative L2, and the gradients of a
+    dozen parameters spread over the depth of both stacks <= 5e-2 relative L2."""
+    from oracle import vacnic_oracle as O
+    from vacnic_amd import streams, synthetic
+    from vacnic_amd.config import bart_large_vit_l14
+    from vacnic_amd.training import TrainArgs, build_models, forward_losses, to_device
+    cfg, vcfg = bart_large_vit_l14(dropout=0.0)
+    streams.enable(True)
+    model, guide, _ = build_models(cfg, vcfg, init="synthetic", seed=0)
+    model.train()                                            # dropout is 0: train mode only keeps the autograd graph
+    batch = synthetic.make_batch(cfg, 2, S=512, T=64, seed=41)
+    total, out4, out = forward_losses(model, guide, to_device(batch, "cuda"), TrainArgs())
+    with torch.autograd.set_multithreading_enabled(False):
+        total.backward()
+    streams.join_all()
+    torch.cuda.synchronize()
+    streams.enable(False)
+    sd = synthetic.make_state_dict(synthetic.mmbart_param_shapes(cfg), seed=1)
+    sd_g = synthetic.make_state_dict(synthetic.guide_bart_param_shapes(cfg), seed=2)
+    sd_c = synthetic.make_state_dict(synthetic.clip_visual_param_shapes(vcfg), seed=4, std=0.05)
+    for v in sd.values():
+        v.requires_grad_(True)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    ref = O.train_losses(sd, sd_g, sd_c, cfg, vcfg, batch)
+    ref["loss"].backward()
+    for i, k in ((0, "loss"), (1, "txt"), (2, "secla"), (3, "colam")):
+        assert abs(out4[i].item() - ref[k].item()) <= 1e-2 * abs(ref[k].item()) + 1e-4, (k, out4[i].item(), ref[k].item())
+    r = rel(out["hidden_states_face"], ref["out"]["hidden_states_face"])
+    assert r <= 2e-2, ("hidden_states_face", r)
+    r = rel(out["decoder_hidden_states"][-1], ref["out"]["decoder_hidden_states"][-1])
+    assert r <= 2e-2, ("dec_last", r)
+    names = ["model.encoder.layers.0.fc1.weight", "model.encoder.layers.5.fc2.weight", "model.encoder.layers.11.fc1.weight",
+             "model.encoder.layers.0.self_attn.q_proj.weight", "model.encoder.layers.11.self_attn.out_proj.weight",
+             "model.encoder.layers.3.cross_attn_img_ner.out_proj.weight", "model.encoder.layers.7._face_up.weight",
+             "model.encoder.layers.9.self_attn_img_name.v_proj.weight", "model.encoder.layers.6.ner_map_up.weight",
+             "model.decoder.layers.0.encoder_attn.k_proj.weight", "model.decoder.layers.6.encoder_attn.v_proj.weight",
+             "model.decoder.layers.11.fc2.weight", "model.decoder.layers.11.self_attn.q_proj.weight",
+             "model.encoder.prompt_mlp.model.0.weight", "model.encoder.visual_map.weight", "model.encoder.layers.2.final_layer_norm.weight",
+             "model.decoder.layers.5.encoder_attn_layer_norm.bias", "model.encoder.embed_positions.weight", "model.shared.weight"]
+    params = dict(model.named_parameters())
+    worst = []
+    for n in names:
+        og = sd[n].grad
+        assert og is not None and og.abs().max() > 0, n
+        r = rel(params[n].grad, og)
+        worst.append((r, n))
+        assert r <= 5e-2, f"grad {n}: rel L2 err {r:.3g}"
+    worst.sort(reverse=True)
+    print("cfg2 full depth: losses", out4.tolist(), "worst grads", worst[:4])
 
 
 def test_cfg2_full_size_step_properties():

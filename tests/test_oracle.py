@@ -163,7 +163,9 @@ def test_oracle_greedy_decode_consistent_with_teacher_forcing():
 
 
 GEN_CASES = [(5, 2.0, {}), (5, 1.0, {}), (1, 1.0, dict(min_length=4)), (5, 1.0, dict(min_length=4)),
-             (4, 2.0, dict(min_length=3, no_repeat_ngram_size=2)), (3, 0.5, dict(min_length=5, no_repeat_ngram_size=3, early_stopping=True))]
+             (4, 2.0, dict(min_length=3, no_repeat_ngram_size=2)), (3, 0.5, dict(min_length=5, no_repeat_ngram_size=3, early_stopping=True)),
+             # the generation defaults of the facebook/bart-* hub checkpoints (config.HUB_GENERATION_DEFAULTS) at config 5's beam / length penalty
+             (5, 2.0, dict(no_repeat_ngram_size=3, early_stopping=True, forced_bos_token_id=0))]
 
 
 def gen_inputs():

@@ -113,7 +113,19 @@ def run(args, batches=None):
                        **PLM[args.plm_type]).validate()
     vcfg = ClipVisionConfig(**vkw)
     model, guide, _ = build_models(cfg, vcfg, device="cuda", seed=int(args.seed) % (2 ** 31), init="device")
-    total_steps = args.num_epoch * args.steps_per_epoch          # TRAIN:99 (not divided by world size there either)
+    # Steps per epoch: the reference derives num_training_steps from the dataset (num_epoch * train_size / batch, TRAIN:99); with
+    # a real shard an epoch is len(loader) steps, and that value — not the synthetic driver's --steps_per_epoch — must size the
+    # linear schedule and the resume arithmetic (a schedule sized for 20 steps would sit at lr = 0 for the rest of the run).
+    shard_loader = None
+    steps_per_epoch = int(args.steps_per_epoch)
+    if batches is None and args.data_type == "shard":
+        from vacnic_amd import data
+        shard_loader = data.PrefetchLoader(data.ShardReader(os.path.join(args.data_dir, "train.vshard")), args.train_batch_size, rank=rank,
+                                           world=world, seed=int(args.seed) % 65536)
+        steps_per_epoch = len(shard_loader)
+        if steps_per_epoch <= 0:
+            raise ValueError("the training shard holds fewer samples than one global batch")
+    total_steps = int(args.num_epoch) * steps_per_epoch          # TRAIN:99 (not divided by world size there either)
     targs = TrainArgs(lr_bart=args.lr_bart, weight_decay=args.weight_decay, warmup_rate=args.warmup_rate,
                       num_training_steps=total_steps, margin=args.margin, alpha=args.alpha,
                       mapping_loss_weight=args.mapping_loss_weight, use_secla=args.use_secla, no_mapping=args.no_mapping,
@@ -126,24 +138,24 @@ def run(args, batches=None):
     start_step = 0
     if args.resume:
         from vacnic_amd import checkpoint
-        start_step = int(checkpoint.load_checkpoint(args.resume, net, opt)["step"])
+        start_step = int(checkpoint.load_checkpoint(args.resume, net, opt, rank=rank)["step"])
         step = start_step
-    for epoch in range(start_step // args.steps_per_epoch, int(args.num_epoch)):
+    for epoch in range(start_step // steps_per_epoch, int(args.num_epoch)):
         if batches is not None:
             it = batches
-        elif args.data_type == "shard":
+        elif shard_loader is not None:
             # packed pre-tokenised shard (vacnic_amd/data.py): sampler + collate + pinned staging + async H2D in the loader
-            from vacnic_amd import data
-            it = data.PrefetchLoader(data.ShardReader(os.path.join(args.data_dir, "train.vshard")), args.train_batch_size, rank=rank,
-                                     world=world, seed=int(args.seed) % 65536)
+            it = shard_loader
             it.set_epoch(epoch)
         else:
             it = (synthetic.make_batch(cfg, args.train_batch_size, S=args.article_max_length, T=min(64, args.caption_max_length),
-                                       seed=int(args.seed) % 65536, rank=rank, step=epoch * args.steps_per_epoch + i)
-                  for i in range(args.steps_per_epoch))
+                                       seed=int(args.seed) % 65536, rank=rank, step=epoch * steps_per_epoch + i)
+                  for i in range(steps_per_epoch))
         for bi, batch in enumerate(it):
-            if epoch * args.steps_per_epoch + bi < start_step:
+            if epoch * steps_per_epoch + bi < start_step:
                 continue                                            # already consumed before the checkpoint
+            if batches is None and step >= total_steps:
+                raise RuntimeError(f"step {step} beyond the schedule's {total_steps} training steps: the learning rate would be 0")
             ready = None
             if isinstance(batch, tuple):                            # (device batch, copy-stream event) from the PrefetchLoader
                 batch, ready = batch
@@ -167,14 +179,14 @@ def run(args, batches=None):
                 min_val_loss = val_loss
                 os.makedirs(args.out_dir, exist_ok=True)
                 from vacnic_amd import checkpoint
-                checkpoint.save_checkpoint(os.path.join(args.out_dir, args.experiment_name + ".pt"), net, opt, step=step, config=dict(cfg.__dict__), vision=dict(vcfg.__dict__))
+                checkpoint.save_checkpoint(os.path.join(args.out_dir, args.experiment_name + ".pt"), net, opt, step=step, rank=rank, config=dict(cfg.__dict__), vision=dict(vcfg.__dict__))
                 with open(os.path.join(args.out_dir, args.experiment_name + "v.json"), "w") as f:
                     json.dump(vdict, f)
     if args.test_steps > 0 and rank == 0:
         # TRAIN:480-530,845-860: beam-search captions for the test split, written next to the checkpoints
         tb = (synthetic.make_batch(cfg, args.test_batch_size, S=args.article_max_length, T=min(64, args.caption_max_length),
                                    seed=(int(args.seed) + 104729) % 65536, rank=0, step=i) for i in range(args.test_steps))
-        tdict = gen_caption_from_loader_bart(net, tb, args.beam_size, args.max_length)
+        tdict = gen_caption_from_loader_bart(net, tb, args.beam_size, args.max_length, plm_type=args.plm_type)
         if args.out_dir:
             os.makedirs(args.out_dir, exist_ok=True)
             with open(os.path.join(args.out_dir, args.experiment_name + ".json"), "w") as f:
@@ -184,7 +196,7 @@ def run(args, batches=None):
     if rank == 0 and args.out_dir:
         os.makedirs(args.out_dir, exist_ok=True)
         from vacnic_amd import checkpoint          # MFULL-named state_dict + optimizer/schedule/RNG (TRAIN:472 pickles the module object)
-        checkpoint.save_checkpoint(os.path.join(args.out_dir, args.experiment_name + "last.pt"), net, opt, step=step, config=dict(cfg.__dict__), vision=dict(vcfg.__dict__))
+        checkpoint.save_checkpoint(os.path.join(args.out_dir, args.experiment_name + "last.pt"), net, opt, step=step, rank=rank, config=dict(cfg.__dict__), vision=dict(vcfg.__dict__))
     if world > 1:
         dist.destroy_process_group()
     return hist

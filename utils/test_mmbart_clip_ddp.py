@@ -99,7 +99,7 @@ def run(args):
                                         rank=0, step=i) for i in steps)
     torch.cuda.synchronize()
     t0 = time.time()
-    local_out = gen_caption_from_loader_bart(model, batches, args.beam_size, args.max_length, length_penalty=args.length_penalty)
+    local_out = gen_caption_from_loader_bart(model, batches, args.beam_size, args.max_length, length_penalty=args.length_penalty, plm_type=args.plm_type)
     torch.cuda.synchronize()
     dt = time.time() - t0
     keyed = {(steps[k] if steps is not None else k * world + rank): v for k, v in local_out.items()}

@@ -7,7 +7,7 @@ same config loads it and vice versa), plus what a bit-for-bit continuation needs
   model      {reference parameter name: fp32 tensor}   (the fp32 master copies; the bf16 shadow is derived)
   optimizer  {"exp_avg": {name: tensor}, "exp_avg_sq": {name: tensor}, "lr": float, "step": int}   — torch.optim.AdamW layout
   schedule   {"base_lr", "num_warmup_steps", "num_training_steps"}
-  rng        {"base", "counter", "device_counter"}      — Philox dropout seeds (ops.Rng)
+  rng        {"seed", "counter", "device_counter"}      — Philox dropout seeds (ops.Rng); `seed` is rank-free, rank r uses seed + r
   meta       {"format": 1, "step": int, ...caller extras}
 Everything is moved to the CPU before `torch.save`, so a checkpoint loads on any box."""
 import torch
@@ -56,19 +56,23 @@ def optimizer_state(model, optimizer):
     return {"exp_avg": ea, "exp_avg_sq": es, "lr": float(hyper[0]), "step": int(hyper[1])}
 
 
-def save_checkpoint(path, model, optimizer=None, step=0, **extra):
+def save_checkpoint(path, model, optimizer=None, step=0, rank=0, **extra):
+    """rank: the saving process's data-parallel rank (its dropout seed offset)."""
     ck = {"model": model_state(model), "meta": dict(extra, format=FORMAT, step=int(step))}
     if optimizer is not None:
         ck["optimizer"] = optimizer_state(model, optimizer)
         ck["schedule"] = {"base_lr": optimizer.lr, "num_warmup_steps": optimizer.warmup, "num_training_steps": optimizer.total,
                           "weight_decay": optimizer.wd, "betas": tuple(optimizer.betas), "eps": optimizer.eps}
     dev = ops.Rng.dev
-    ck["rng"] = {"base": ops.Rng.base, "counter": ops.Rng.counter, "device_counter": int(dev.item()) if dev is not None else 0}
+    # `seed` is the run's seed WITHOUT the saving rank's offset (the trainer seeds rank r with seed + r): a resumed rank
+    # re-derives its own base, so the data-parallel replicas keep drawing different dropout masks
+    ck["rng"] = {"seed": (ops.Rng.base - int(rank)) & 0xFFFFFFFF, "counter": ops.Rng.counter,
+                 "device_counter": int(dev.item()) if dev is not None else 0}
     torch.save(ck, path)
     return ck
 
 
-def load_checkpoint(path_or_dict, model, optimizer=None, strict=True):
+def load_checkpoint(path_or_dict, model, optimizer=None, strict=True, rank=0):
     """restore weights (+ optimizer moments, LR-schedule position and dropout RNG when an optimizer is given); returns meta."""
     ck = torch.load(path_or_dict, map_location="cpu", weights_only=False) if isinstance(path_or_dict, (str, bytes)) or hasattr(path_or_dict, "read") else path_or_dict
     if ck.get("meta", {}).get("format") != FORMAT:
@@ -98,7 +102,9 @@ def load_checkpoint(path_or_dict, model, optimizer=None, strict=True):
         optimizer.hyper.copy_(torch.tensor([o["lr"], float(o["step"])]))
         r = ck.get("rng")
         if r is not None:
-            ops.Rng.base, ops.Rng.counter = r["base"], r["counter"]
+            seed = r["seed"] if "seed" in r else r["base"]          # "base": checkpoints written before the per-rank fix
+            ops.Rng.base = (int(seed) + int(rank)) & 0xFFFFFFFF      # per-rank base: replicas must not share dropout masks
+            ops.Rng.counter = r["counter"]
             if optimizer.hyper.is_cuda:
                 ops.Rng.device_counter().fill_(r["device_counter"])
     return ck["meta"]

@@ -101,3 +101,19 @@ def bart_base_vit_b32(**kw):
                      decoder_attention_heads=12, encoder_ffn_dim=3072, decoder_ffn_dim=3072,
                      enc_fusion_layer=list(range(6)), dim_common=768, only_image=True, clip_width=768, **kw).validate()
     return c, ClipVisionConfig(width=768, layers=12, patch_size=32, output_dim=512)
+
+# Generation defaults that live in the hub checkpoints' config.json (NOT in BartConfig's own defaults): a model built by
+# `from_pretrained(plm_type)` (TRAIN:743) carries them, and transformers 4.18 `generate()` falls back to them for every argument
+# the caller leaves out — the reference's trainers pass only num_beams / max_length (TRAIN:513-520), its stand-alone generator also
+# length_penalty (DDPINF:38,867).  The files are unreadable offline; these are the published values of
+# facebook/bart-base and facebook/bart-large (the fp32 re-upload copies bart-large's).
+HUB_GENERATION_DEFAULTS = {
+    "facebook/bart-base": dict(no_repeat_ngram_size=3, early_stopping=True, forced_bos_token_id=0, forced_eos_token_id=2),
+    "facebook/bart-large": dict(no_repeat_ngram_size=3, early_stopping=True, forced_bos_token_id=0, forced_eos_token_id=2),
+    "patrickvonplaten/bart-large-fp32": dict(no_repeat_ngram_size=3, early_stopping=True, forced_bos_token_id=0, forced_eos_token_id=2),
+}
+
+
+def generation_defaults(plm_type=None):
+    """kwargs for generate() that reproduce the reference's `model.generate(num_beams, max_length)` on a hub checkpoint."""
+    return dict(HUB_GENERATION_DEFAULTS.get(plm_type or "facebook/bart-large", HUB_GENERATION_DEFAULTS["facebook/bart-large"]))

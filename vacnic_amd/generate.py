@@ -137,9 +137,10 @@ class DecodeSession:
     position is captured on first use and replayed afterwards, which removes the ~170 Python->HIP launches per token that
     bound the eager loop."""
 
-    def __init__(self, model, R, S, max_length, nb, ngram, min_length, forced_eos, eos):
+    def __init__(self, model, R, S, max_length, nb, ngram, min_length, forced_eos, eos, forced_bos=None):
         self.model, self.R, self.nb, self.max_length = model, R, nb, max_length
         self.ngram, self.min_length, self.forced_eos, self.eos = ngram, min_length, forced_eos, eos
+        self.forced_bos = forced_bos
         dev = model.emb16_pad.device
         self.dec = CachedDecoder(model, R, S, max_length, reorders=nb > 1)
         self.ids_s = torch.zeros((R, 1), device=dev, dtype=torch.long)
@@ -159,6 +160,8 @@ class DecodeSession:
         logits = self.dec.step(self.ids_s, t)
         cur_len = t + 1
         forced = self.forced_eos if (self.forced_eos is not None and cur_len == self.max_length - 1) else -1
+        if self.forced_bos is not None and cur_len == 1:             # ForcedBOSTokenLogitsProcessor (runs before ForcedEOS in HF)
+            forced = self.forced_bos if forced < 0 else forced
         V = self.model.V
         return K.beam_topk(logits, V, min(2 * self.nb, V), beam_scores=self.scores_s, bans=self.bans_s, eos=self.eos,
                            suppress_eos=cur_len < self.min_length, forced_token=forced)
@@ -197,10 +200,13 @@ class DecodeSession:
 
 @torch.no_grad()
 def generate(model, input_ids=None, attention_mask=None, num_beams=1, max_length=20, length_penalty=1.0, early_stopping=False,
-             no_repeat_ngram_size=0, min_length=0, forced_eos_token_id="config", image_features=None, face_features=None,
-             face_mask=None, name_ids=None, name_mask=None, add_ner_ffn=True, use_graphs=True, **unused):
+             no_repeat_ngram_size=0, min_length=0, forced_eos_token_id="config", forced_bos_token_id=None, image_features=None,
+             face_features=None, face_mask=None, name_ids=None, name_mask=None, add_ner_ffn=True, use_graphs=True, **unused):
     """GenerationMixin.generate(do_sample=False) semantics of transformers 4.18 for this model (greedy = 1 beam).
-    Returns int64 [B, L] starting with decoder_start_token_id, padded with pad_token_id."""
+    Returns int64 [B, L] starting with decoder_start_token_id, padded with pad_token_id.
+    Keyword defaults are the LIBRARY defaults; the defaults a hub checkpoint's config.json adds on top (what the reference's
+    `model.generate(num_beams, max_length)` inherits after from_pretrained, TRAIN:513-520) are config.HUB_GENERATION_DEFAULTS and
+    are passed explicitly by the trainer-level callers (training.gen_caption_from_loader_bart, utils/test_mmbart_clip_ddp.py)."""
     cfg = model.config
     if model.arena is None:
         raise RuntimeError("call model.finalize(device) first")
@@ -217,11 +223,12 @@ def generate(model, input_ids=None, attention_mask=None, num_beams=1, max_length
                               name_mask=name_mask, face_features=face_features, face_mask=face_mask, add_ner_ffn=add_ner_ffn)
     enc_h = enc["last_hidden_state"]
     S, d = enc_h.shape[1], enc_h.shape[2]
-    key = (R, S, max_length, nb, no_repeat_ngram_size, min_length, forced_eos_token_id)
+    key = (R, S, max_length, nb, no_repeat_ngram_size, min_length, forced_eos_token_id, forced_bos_token_id)
     sessions = model.__dict__.setdefault("_decode_sessions", {})
     ses = sessions.get(key)
     if ses is None:
-        ses = sessions[key] = DecodeSession(model, R, S, max_length, nb, no_repeat_ngram_size, min_length, forced_eos_token_id, eos)
+        ses = sessions[key] = DecodeSession(model, R, S, max_length, nb, no_repeat_ngram_size, min_length, forced_eos_token_id, eos,
+                                            forced_bos=forced_bos_token_id)
     ses.dec.begin(enc_h, mask_u8, nb)
 
     seqs = [[start] for _ in range(R)]

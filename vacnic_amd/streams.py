@@ -45,7 +45,11 @@ def keep(*tensors):
     k = _state["keep"]
     k.extend(tensors)
     if len(k) > 8192:
+        # early release: every stream a kept tensor may have been allocated on (the compute stream and the branch stream, whose
+        # blocks go back to THEIR pools) must be ordered behind the weight-gradient stream's reads before the references drop
         torch.cuda.current_stream().wait_stream(_state["wgrad"])
+        if _state["branch"] is not None:
+            _state["branch"].wait_stream(_state["wgrad"])
         k.clear()
 
 

@@ -150,6 +150,8 @@ def forward_losses(model, guide, batch, args: TrainArgs, ready=None, towers=None
     main = torch.cuda.current_stream()
     aux, vis = streams.aux_stream(), streams.vit_stream()
     if aux is None:
+        if ready is not None:
+            main.wait_event(ready)           # single-stream schedule: the loader's copy stream still has to hand the batch over
         src_mask, _ = K.prep_ids(src, cfg.pad_token_id)                                      # create_src_mask_bart, TRAIN:268
         tgt_mask, tgt_in = K.prep_ids(tgt, cfg.pad_token_id, start_id=cfg.eos_token_id)     # shift_tokens_right, TRAIN:267,296
         img_cls = extract_clip_img_feat(net.clip_model, batch["img_tensor"])[feat]            # TRAIN:274-276
@@ -273,19 +275,23 @@ def eval_epoch(model, batches, device="cuda"):
 
 
 @torch.no_grad()
-def gen_caption_from_loader_bart(model, batches, beam_size, max_length, device="cuda", length_penalty=1.0):
+def gen_caption_from_loader_bart(model, batches, beam_size, max_length, device="cuda", length_penalty=1.0, plm_type=None, **gen_kw):
     """TRAIN:480-530 (the generation half; BLEU/ROUGE/CIDEr/METEOR scoring and detokenisation are outside SURVEY §8):
     out_dict[step] = {"gt": target ids, "gen": generated ids} with `model.generate(num_beams=beam_size, max_length=max_length)`;
-    `length_penalty` is the extra knob of the stand-alone generator (DDPINF:38,867)."""
+    `length_penalty` is the extra knob of the stand-alone generator (DDPINF:38,867).  Arguments the reference leaves to the model's
+    config (no_repeat_ngram_size, early_stopping, forced BOS/EOS) default to the hub checkpoint's (config.HUB_GENERATION_DEFAULTS,
+    keyed by `plm_type`); `gen_kw` overrides them."""
     net = model.module if isinstance(model, DistributedDataParallel) else model
     was_training = net.training
     net.eval()
     out_dict = {}
+    from .config import generation_defaults
+    gkw = dict(generation_defaults(plm_type), **gen_kw)        # what `model.generate(num_beams, max_length)` inherits from the hub config
     for step, batch in enumerate(batches):
         batch = to_device(batch, device)
         src, src_mask, feats, kw = _model_inputs(net, batch)
         gen = net.generate(input_ids=src, attention_mask=src_mask, num_beams=beam_size, max_length=max_length, image_features=feats,
-                           length_penalty=length_penalty, add_ner_ffn=True, **kw)
+                           length_penalty=length_penalty, add_ner_ffn=True, **kw, **gkw)
         out_dict[step] = {"gt": batch["caption_ids"].tolist(), "gen": gen.tolist()}
     net.train(was_training)
     return out_dict
