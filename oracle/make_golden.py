@@ -361,9 +361,39 @@ def run_collate():
     np.savez_compressed(os.path.join(OUT, "collate.npz"), **rec)
 
 
+def run_checkpoint_readback(mfull, train):
+    """SURVEY §8f-3 "can be read back by the reference": a checkpoint written by vacnic_amd/checkpoint.py (oracle/ckpt_case.py)
+    is loaded into the REAL reference class with load_state_dict(strict=True) — no renaming, no missing or unexpected key —
+    and the reference's teacher-forced logits on a seeded batch are recorded."""
+    from oracle import ckpt_case
+    cfg, ck, batch, img = ckpt_case.make_checkpoint()
+    m = build_ref_model(mfull, cfg, {k: v for k, v in ck["model"].items() if k in synthetic.mmbart_param_shapes(cfg)})
+    fresh = mfull.BartForMultiModalGeneration(bart_config(cfg), enc_fusion_layer=list(cfg.enc_fusion_layer), dim_common=cfg.dim_common,
+                                              img_size=768, prompt_mlp_type=cfg.prompt_mlp_type, prompt_size=cfg.prompt_size, clip_model=None,
+                                              max_ner_type_len=cfg.max_ner_type_len, max_ner_type_len_gt=cfg.max_ner_type_len_gt,
+                                              only_image=cfg.only_image)
+    res = fresh.load_state_dict(ck["model"], strict=True)          # the checkpoint AS WRITTEN, into an untouched reference instance
+    assert not res.missing_keys and not res.unexpected_keys, res
+    fresh.eval()
+    src, tgt = batch["article_ids"], batch["caption_ids"]
+    kw = dict(face_features=batch["face_emb"], face_mask=train.create_src_mask_bart(batch["face_emb"][:, :, -1]),
+              name_ids=batch["names_art_ids"], name_mask=train.create_src_mask_bart(batch["names_art_ids"]), add_ner_ffn=True)
+    with torch.no_grad():
+        outs = [mm(input_ids=src, attention_mask=train.create_src_mask_bart(src), decoder_input_ids=train.shift_tokens_right(tgt, 1, 2),
+                   image_features=img, **kw)["logits"] for mm in (fresh, m)]
+    assert torch.equal(outs[0], outs[1]), "strict load of the checkpoint == explicit tie + named load"
+    rec = {"n_keys": np.array(len(ck["model"])), "step": np.array(ck["meta"]["step"]), "argmax": outs[0].argmax(-1).numpy()}
+    rec["logits_s"], rec["logits_c"] = slices(outs[0])
+    np.savez_compressed(os.path.join(OUT, "checkpoint_readback.npz"), **rec)
+    print("checkpoint readback ok:", len(ck["model"]), "tensors, logits checksum", rec["logits_c"])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     mfull, mvis, train, BatchSoftmax = import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "checkpoint":
+        run_checkpoint_readback(mfull, train)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "generate":
         run_generate_case(mfull, train)
         return
@@ -378,6 +408,7 @@ def main():
         return
     run_collate()
     run_helpers(train, BatchSoftmax)
+    run_checkpoint_readback(mfull, train)
     run_generate_case(mfull, train)
     run_clip_crosscheck()
     run_full_case("mfull_d768", mfull, train, BatchSoftmax, small_cfg(), B=3, S=48, T=12, F=3)

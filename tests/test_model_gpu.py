@@ -501,6 +501,34 @@ def test_cfg4_long_article_1024_tokens_step_and_oracle():
     assert hist[-1][1] < hist[0][1], hist
 
 
+def test_checkpoint_round_trip_product_to_reference_to_product():
+    """SURVEY §8f-3 on the GPU: the checkpoint of oracle/ckpt_case.py (written by vacnic_amd/checkpoint.py, loaded strict into the
+    REAL reference for tests/golden/checkpoint_readback.npz) is restored into the HIP model, whose teacher-forced logits must match
+    what the reference computed from the same file."""
+    from oracle import ckpt_case
+    from vacnic_amd import checkpoint, kernels as K
+    from vacnic_amd.config import ClipVisionConfig
+    from vacnic_amd.training import build_models
+    g = np.load(os.path.join(G, "checkpoint_readback.npz"))
+    cfg, ck, batch, img = ckpt_case.make_checkpoint()
+    model, _, _ = build_models(cfg, ClipVisionConfig(width=128, layers=1, patch_size=16, image_size=32, output_dim=64), init="synthetic",
+                               seed=99, with_guide=False)                      # different weights before the restore
+    meta = checkpoint.load_checkpoint(ck, model)
+    assert meta["step"] == 3
+    model.eval()
+    dev = {k: v.cuda() for k, v in batch.items()}
+    mask, _ = K.prep_ids(dev["article_ids"], 1)
+    nmask, _ = K.prep_ids(dev["names_art_ids"], 1)
+    _, tgt_in = K.prep_ids(dev["caption_ids"], 1, start_id=2)
+    with torch.no_grad():
+        out = model(input_ids=dev["article_ids"], attention_mask=mask, decoder_input_ids=tgt_in, image_features=img.cuda(),
+                    face_features=dev["face_emb"], face_mask=K.face_mask(dev["face_emb"]), name_ids=dev["names_art_ids"], name_mask=nmask)
+    want = g["logits_s"]
+    err = np.abs(slices(out["logits"]) - want)
+    assert err.max() <= 3e-2 * np.abs(want).max() and np.linalg.norm(err) <= 1e-2 * np.linalg.norm(want), (err.max(), np.abs(want).max())
+    assert (out["logits"].float().argmax(-1).cpu().numpy() == g["argmax"]).mean() >= 0.97
+
+
 def test_cfg2_full_depth_matches_oracle_losses_states_and_gradients():
     """BASELINE configs[1] at FULL depth and width — BART-large 12+12 layers, d=1024, CLIP ViT-L/14 (24 layers), full VACNIC
     (clipcap prompt, SECLA, CoLaM a=0.5 m=1.0), 512-token articles, 64-token captions, dropout 0 — at batch 2, where the CPU

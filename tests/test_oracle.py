@@ -188,3 +188,24 @@ def test_oracle_beam_search_matches_hf_generate_over_reference_logits():
     for i, (nb, lp, extra) in enumerate(GEN_CASES):
         got = O.beam_search_decode(sd, cfg, src, mask, img, nb, 12, lp, forced_eos_token_id=2, norm="v5", **extra, **kw)
         assert np.array_equal(got.numpy(), g[f"seq{i}"]), (i, got.tolist(), g[f"seq{i}"].tolist())
+
+
+def test_checkpoint_written_by_the_product_is_read_back_by_the_reference():
+    """tests/golden/checkpoint_readback.npz = logits of the REAL reference class after
+    `load_state_dict(ck["model"], strict=True)` of a checkpoint written by vacnic_amd/checkpoint.py (oracle/make_golden.py
+    ::run_checkpoint_readback).  Here the same checkpoint is rebuilt (seeded) and replayed through the oracle: the tensors the
+    product writes under the reference's names are exactly what the reference reads."""
+    from oracle import ckpt_case
+    g = np.load(os.path.join(G, "checkpoint_readback.npz"))
+    cfg, ck, batch, img = ckpt_case.make_checkpoint()
+    assert len(ck["model"]) == int(g["n_keys"]) and ck["meta"]["step"] == int(g["step"])
+    assert {"model.encoder.embed_tokens.weight", "model.decoder.embed_tokens.weight", "lm_head.weight", "final_logits_bias"} <= set(ck["model"])
+    assert torch.equal(ck["model"]["lm_head.weight"], ck["model"]["model.shared.weight"])
+    sd = {k: v for k, v in ck["model"].items() if k in synthetic.mmbart_param_shapes(cfg)}
+    src, tgt = batch["article_ids"], batch["caption_ids"]
+    with torch.no_grad():
+        out = O.mmbart_forward(sd, cfg, src, O.create_src_mask_bart(src), O.shift_tokens_right(tgt, 1, 2), img,
+                               face_features=batch["face_emb"], face_mask=O.create_src_mask_bart(batch["face_emb"][:, :, -1]),
+                               name_ids=batch["names_art_ids"], name_mask=O.create_src_mask_bart(batch["names_art_ids"]))
+    check("logits", out["logits"], g)
+    assert np.array_equal(out["logits"].argmax(-1).numpy(), g["argmax"])
