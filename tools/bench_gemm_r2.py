@@ -12,7 +12,8 @@ from vacnic_amd import kernels as K
 
 dev = "cuda"
 r = lambda *s: (torch.randn(*s, device=dev) * 0.5).bfloat16()
-VARIANTS = (("new", 256), ("np", 256 + 64000), ("old", 256 + 64000 + 16000), ("old-persist", 256 + 16000))
+VARIANTS = (("new", 256), ("np", 256 + 64000), ("old-epi", 256 + 64000 + 16000), ("half-line DMA (wrong results)", 256 + 512000))
+CHECK = {"new", "np", "old-epi"}
 
 
 def timed(fn, iters):
@@ -50,7 +51,7 @@ def case(name, M, N, Kd, lay="nn", **epi):
         torch.cuda.synchronize()
         if ref is None:
             ref = out.float().clone()
-        else:
+        elif vn in CHECK:
             d = (out.float() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-6)
             assert d < 2e-2, f"{name} {vn}: variants disagree by {d}"
     rounds = 5

@@ -94,6 +94,36 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int rbase, int
   }
 }
 
+// ---- "half-row" staging of a K-CONTIGUOUS operand for the ping-pong loop: stage s = (K-step J = s >> 1 of 64 k, row half s & 1)
+// holds rows [half * ROWS/2, +ROWS/2) x 64 k as 128-byte LDS rows (chunk' = chunk ^ (row & 7)).  Every LDS-DMA piece then reads
+// 8 rows x 128 contiguous bytes = whole cache lines.  With 32-wide K stages a piece read 16 rows x 64 bytes: each 128-byte line
+// crossed the CU's vector L1 twice (once per K half, a stage apart), and the feed ran at 55-58 GB/s per CU against the
+// 76-78 GB/s of whole-line rows (tools/dma_probe.hip, profiles/r2_dma_probe.txt) — below what the MFMAs of a 256x256 tile eat.
+template <int ROWS, int NWAVE>
+__device__ __forceinline__ void stage_half(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, int r0, int R, int k0, int kend, int ld,
+                                           int half, int wave, int lane, bool ab_halfline = false) {
+  constexpr int PIECES = (ROWS / 2) * 128 / 1024 / NWAVE;
+  static_assert(PIECES >= 1, "tile too small for this wave count");
+#pragma unroll
+  for (int i = 0; i < PIECES; ++i) {
+    const int blk = wave * PIECES + i;
+    const int row = blk * 8 + (lane >> 3);               // row inside the half
+    const int kch = (lane & 7) ^ (row & 7);
+    int gr = r0 + half * (ROWS / 2) + row, gk = k0 + kch * 8;
+    if (ab_halfline) {       // A/B (debug bit 9, results are WRONG): the round-1 access shape, 16 rows x 64 B per piece, same bytes
+      gr = r0 + blk * 16 + (lane >> 2); gk = k0 + half * 32 + (lane & 3) * 8;
+    }
+    const int voff = (gr < R && gk < kend) ? (int)(((unsigned)gr * (unsigned)ld + (unsigned)gk) * 2u) : OOB;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + blk * 1024), 16, voff, 0, 0, 0);
+  }
+}
+// fragment of rows rloc..rloc+15 (inside the half), k-substep kk (0/1) of the stage's 64 k
+__device__ __forceinline__ bf16x8 read_half(const char* lds_tile, int rloc, int kk, int lane) {
+  const int row = rloc + (lane & 15);
+  const int chunk = kk * 4 + (lane >> 4);
+  return *(const bf16x8*)(lds_tile + row * 128 + ((chunk ^ (row & 7)) << 4));
+}
+
 // Epilogue on 8 consecutive outputs of one row (read back from the LDS-staged C tile): bias, saved
 // pre-activation, activation or fused activation-backward, residual, then a 16-byte (bf16) /
 // 2x16-byte (f32) store or 8 f32 atomics on 32 contiguous bytes.
@@ -293,11 +323,24 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
   static_assert(LOADS * (NSTAGE - 2) <= 63, "vmcnt immediate");
   constexpr bool PIPED = PIPE && BKT == 64 && NSTAGE == 2;
   constexpr int PRO = PIPED ? 2 : NSTAGE - 1;            // tiles staged before the loop
+  // ping-pong ring: 5 slots (160 KiB: all of a CU's LDS).  Stage s of a K-contiguous operand = row half (s & 1) of the 64-wide
+  // K-step s >> 1 (stage_half); stage s of a K-strided operand = its 32 k-rows [32 s, 32 s + 32) of all rows, as before.
+  constexpr int NSLOT = 5;
+  auto stage_pp = [&](const Work& k, int s, char* slot, int wave_, int lane_) {
+    if constexpr (XKS) stage_tile<true, BM, BKT, NWAVE>(xs, slot, k.m0, RX, k.kbeg + s * BKT, k.kend, p.ldx, wave_, lane_);
+    else stage_half<BM, NWAVE>(xs, slot, k.m0, RX, k.kbeg + (s >> 1) * 64, k.kend, p.ldx, s & 1, wave_, lane_, (p.debug & 512) != 0);
+    if constexpr (WKS) stage_tile<true, BN, BKT, NWAVE>(ws, slot + XT, k.n0, RW, k.kbeg + s * BKT, k.kend, p.ldw, wave_, lane_);
+    else stage_half<BN, NWAVE>(ws, slot + XT, k.n0, RW, k.kbeg + (s >> 1) * 64, k.kend, p.ldw, s & 1, wave_, lane_, (p.debug & 512) != 0);
+  };
   auto prologue = [&](const Work& k, int wave_, int lane_) {
 #pragma unroll
     for (int s = 0; s < PRO; ++s) {
-      stage_tile<XKS, BM, BKT, NWAVE>(xs, smem + s * STAGE, k.m0, RX, k.kbeg + s * BKT, k.kend, p.ldx, wave_, lane_);
-      stage_tile<WKS, BN, BKT, NWAVE>(ws, smem + s * STAGE + XT, k.n0, RW, k.kbeg + s * BKT, k.kend, p.ldw, wave_, lane_);
+      if constexpr (PINGPONG) {
+        stage_pp(k, s, smem + s * STAGE, wave_, lane_);
+      } else {
+        stage_tile<XKS, BM, BKT, NWAVE>(xs, smem + s * STAGE, k.m0, RX, k.kbeg + s * BKT, k.kend, p.ldx, wave_, lane_);
+        stage_tile<WKS, BN, BKT, NWAVE>(ws, smem + s * STAGE + XT, k.n0, RW, k.kbeg + s * BKT, k.kend, p.ldw, wave_, lane_);
+      }
     }
   };
   // bf16 epilogue geometry (256-row tiles): 16-byte chunks per staged row, rows per sweep of the workgroup, sweeps (= 16-byte
@@ -362,13 +405,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
   }
 
   // tile 0 landed (this wave's pieces; the stores counted in `pend` are younger than all prologue loads)
-  if (PINGPONG && pend == NIT) wait_vm_lgkm<LOADS * (PRO - 1) + NIT>();
-  else if (PINGPONG && pend != 0) wait_vm_lgkm<LOADS * (PRO - 1) + 2 * NIT>();
+  // (ping-pong: the first K-step reads stages 0 AND 1, so only stage 2 — and the `pend` stores — may still fly)
+  if (PINGPONG && pend == NIT) wait_vm_lgkm<LOADS + NIT>();
+  else if (PINGPONG && pend != 0) wait_vm_lgkm<LOADS + 2 * NIT>();
+  else if (PINGPONG) wait_vm_lgkm<LOADS>();
   else wait_vm_lgkm<LOADS * (PRO - 1)>();
   __builtin_amdgcn_s_barrier();
   int cur = 0, nxt = NSTAGE - 1;
   if constexpr (PINGPONG) {
-    // Ping-pong K loop (8 waves, two per SIMD; 32-wide K stages in a 4-slot ring).  The waves of a workgroup form two
+    // Ping-pong K loop (8 waves, two per SIMD; 32-wide K substeps over a 5-slot ring of 32-KiB stages).  The waves of a workgroup form two
     // groups, A = waves 0..3 and B = waves 4..7 (SIMD partners), that run the same sequence one interval apart:
     //     A:  MEM(0) | COMP(0) | MEM(1) | COMP(1) | ...
     //     B:    -    | MEM(0)  | COMP(0)| MEM(1)  | ...          ('|' = workgroup barrier)
@@ -377,9 +422,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
     // LDS / vector-memory issue ports, so neither the fragment reads nor the ~60-100-cycle issue cost of an LDS-DMA piece
     // ever stalls the MFMA stream (measured before: MFMA-only loop 1.0 us per 64-K, +0.27 us for the LDS reads, +0.34 us
     // for the DMA issue when both partners do the same thing at the same time).
-    // Ring safety: stage j is read by A in interval 2j and by B in interval 2j+1; MEM(j+1) (intervals 2j+2 / 2j+3) refills
-    // its slot with stage j+4.  A wave leaves MEM(h) only when its own pieces of stage h+1 have landed (vmcnt(8): stages
-    // h+2, h+3 may fly), and a barrier separates that from every later reader.
     static_assert(NWAVE == 8 && LOADS >= 2, "ping-pong loop is written for 8 waves (two per SIMD)");
     // (Issuing part of the DMA pieces in the middle of COMP(h) instead, or staggering the partners' issue points in a 64-wide
     // pipelined loop, measured the same within noise: profiles/r1_gemm_overhead.txt.)
@@ -387,23 +429,45 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
     const int nst = ntile;
     bf16x8 xf[FA], wf[FB];
     if (grp_b) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
-    int rd = 0, wr = 3;
+    // Ring bookkeeping (5 slots, stage s in slot s % 5).  Substep h = K-step J = h >> 1, half kk = h & 1.  MEM(h) reads the
+    // K-contiguous operands from the slots of stages 2J (row half 0) and 2J + 1 (row half 1) at k-offset 32 kk — a wave's X
+    // rows all lie in half wm, its W rows in half wn >> 1 — and the K-strided operands from the slot of stage h; it issues
+    // this wave's pieces of stage h + 3, whose slot (stage h - 2) is dead: the stages of K-step J are read in intervals
+    // 4J .. 4J + 3 (group A: MEM(2J), MEM(2J+1); group B one interval later) and h - 2 belongs to K-step J - 1 for both parities.
+    // Landing: MEM(h + 1) reads stages <= h + 2 when h + 1 is even (a new K-step: both of its stages) and <= h + 1 when odd,
+    // so a wave leaves MEM(h) with at most stage h + 3 (h odd) or h + 2, h + 3 (h even) of its own pieces in flight.
+    int s0 = 0;                                            // slot of stage h
     for (int h = 0; h < nst; ++h) {
-      const char* xr = smem + rd * STAGE;
-      char* xw = smem + wr * STAGE;
+      const int kk = h & 1;
+      const int se = kk ? (s0 == 0 ? NSLOT - 1 : s0 - 1) : s0;                 // slot of stage 2J
+      const int so = kk ? s0 : (s0 + 1 == NSLOT ? 0 : s0 + 1);                 // slot of stage 2J + 1
+      const int sw = s0 + 3 >= NSLOT ? s0 + 3 - NSLOT : s0 + 3;                // slot of stage h + 3
       if (!(p.debug & 128) || h == 0) {
+        if constexpr (XKS) {
 #pragma unroll
-        for (int a = 0; a < FA; ++a) xf[a] = read_frag<XKS, BM, BKT>(xr, wm * TM + a * 16, 0, lane);
+          for (int a = 0; a < FA; ++a) xf[a] = read_frag<true, BM, BKT>(smem + s0 * STAGE, wm * TM + a * 16, 0, lane);
+        } else {
+          static_assert(TM <= BM / 2 && (BM / 2) % TM == 0, "a wave's rows must lie in one row half");
+          const char* xb = smem + ((wm * TM) / (BM / 2) ? so : se) * STAGE;
 #pragma unroll
-        for (int b = 0; b < FB; ++b) wf[b] = read_frag<WKS, BN, BKT>(xr + XT, wn * TN + b * 16, 0, lane);
+          for (int a = 0; a < FA; ++a) xf[a] = read_half(xb, (wm * TM) % (BM / 2) + a * 16, kk, lane);
+        }
+        if constexpr (WKS) {
+#pragma unroll
+          for (int b = 0; b < FB; ++b) wf[b] = read_frag<true, BN, BKT>(smem + s0 * STAGE + XT, wn * TN + b * 16, 0, lane);
+        } else {
+          static_assert(TN <= BN / 2 && (BN / 2) % TN == 0, "a wave's columns must lie in one row half of W");
+          const char* wb = smem + ((wn * TN) / (BN / 2) ? so : se) * STAGE + XT;
+#pragma unroll
+          for (int b = 0; b < FB; ++b) wf[b] = read_half(wb, (wn * TN) % (BN / 2) + b * 16, kk, lane);
+        }
       }
-      if (!(p.debug & 32)) {
-        stage_tile<XKS, BM, BKT, NWAVE>(xs, xw, m0, RX, kbeg + (h + 3) * BKT, kend, p.ldx, wave, lane);
-        stage_tile<WKS, BN, BKT, NWAVE>(ws, xw + XT, n0, RW, kbeg + (h + 3) * BKT, kend, p.ldw, wave, lane);
-      }
-      // stage h+1 must have landed (this wave's pieces); newer ones may fly — and so may, during the first two steps, the
-      // previous tile's stores that were issued between this tile's prologue loads and the loads of stages 3 and 4
-      if (h < 2 && pend != 0) {
+      if (!(p.debug & 32)) stage_pp(wk, h + 3, smem + sw * STAGE, wave, lane);
+      // counted wait (see "Landing"); during MEM(0) the previous tile's stores, issued between this tile's prologue loads and
+      // stage 3, may still fly — by the end of MEM(1) they are older than a stage that must have landed
+      if (kk) {
+        wait_vm_lgkm<LOADS>();
+      } else if (h == 0 && pend != 0) {
         if (pend == NIT) wait_vm_lgkm<2 * LOADS + NIT>();
         else wait_vm_lgkm<2 * LOADS + 2 * NIT>();
       } else {
@@ -423,8 +487,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      rd = (rd + 1) & 3;
-      wr = (wr + 1) & 3;
+      s0 = s0 + 1 == NSLOT ? 0 : s0 + 1;
     }
     if (!grp_b) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
   } else if constexpr (PIPED) {
@@ -582,7 +645,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
   // arithmetic of a bf16 autocast Linear followed by a bf16 elementwise op.
   if constexpr (BM == 256 && BN >= 128) {
     if (!done && q.out_mode == 0 && (q.ldo & 7) == 0 && (q.N & 7) == 0 && !(q.debug & 16)) {
-      static_assert(BM * ROWB <= NSTAGE * STAGE, "bf16 C tile must fit in the operand ring");
+      static_assert(BM * ROWB <= (PINGPONG ? 5 : NSTAGE) * STAGE, "bf16 C tile must fit in the operand ring");
       const bool act_in_regs = q.act != VACNIC_ACT_NONE && !q.preact && !q.dact_src;
       f32x4 bia[FB];
 #pragma unroll
@@ -838,7 +901,7 @@ int launch_gemm(const GemmP& p0, bool xks, bool wks, int zsplits, hipStream_t s)
     if (nwg > ncu) nwg = ncu;
   }
   dim3 grid(nwg), block(64 * WM * WN);
-  constexpr size_t lds = NSTAGE * (BM + BN) * BKT * 2;
+  constexpr size_t lds = (PIPE && BKT == 32 && NSTAGE == 4 ? 5 : NSTAGE) * (BM + BN) * BKT * 2;   // ping-pong: 5-slot ring
   static_assert(lds >= 64 * (BN + 4) * 4, "epilogue staging must fit in the operand buffers");
 #define VAC_LAUNCH(XK, WK)                                                                            \
   do {                                                                                                \
