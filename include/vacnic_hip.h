@@ -305,6 +305,33 @@ int vacnic_gather_rows(const void* src, void* dst, const int64_t* idx, int64_t r
 int vacnic_image_u8_normalize(const uint8_t* src, const uint8_t* flip, float* dst, int64_t B, int64_t H, int64_t W,
                               float mean0, float mean1, float mean2, float std0, float std1, float std2, void* stream);
 
+/*
+ * Fused LM head + cross entropy: logits = h . E^T (+ final_logits_bias) (MFULL:1885,1997) into
+ * CrossEntropyLoss(ignore_index) (TRAIN:287,816) WITHOUT materialising the [R, V] logits.
+ *   vacnic_lmhead_ce_fwd      one GEMM whose epilogue reduces each 256-column tile of a row to an online-softmax pair
+ *                             {max, sum exp} (part[R][part_tiles][2], part_tiles = ceil(V/256)) and picks the target logit
+ *                             (tl[R]); a combine kernel writes row_lse[R] and ACCUMULATES loss_sum / count (both zeroed by
+ *                             the call) over rows whose target != ignore_index.  loss = loss_sum / count.
+ *   vacnic_lmhead_ce_rowp     rowp[R][2] = {row_lse, (target != ignore) * grad_out * grad_scale / count} for the backward.
+ *   vacnic_lmhead_ce_dlogits  recomputes the logits of vocabulary columns [col0, col0 + ncols) and writes
+ *                             dlogits = (softmax - onehot(target)) * rowp[.][1] as bf16 [R][lddl] (columns ncols..round_up(ncols,8)
+ *                             are written as zeros); the caller runs the dh / dE GEMMs on the chunk and re-uses the buffer.
+ */
+typedef struct {
+  const void* h; const void* emb; const float* bias;      /* bf16 [R][ldh], bf16 [>=V][lde] (tied embedding), f32 [V] or NULL */
+  const int64_t* targets;                                 /* [R] */
+  float* part; float* tl; float* row_lse; float* loss_sum; float* count;
+  int64_t R, V, D, ldh, lde, part_tiles, ignore_index;
+} vacnic_lmhead_ce_args;
+int vacnic_lmhead_ce_fwd(const vacnic_lmhead_ce_args* a, void* stream);
+int vacnic_lmhead_ce_rowp(const float* row_lse, const int64_t* targets, const float* count, const float* grad_out,
+                          float grad_scale, float* rowp, int64_t R, int64_t ignore_index, void* stream);
+int vacnic_lmhead_ce_dlogits(const vacnic_lmhead_ce_args* a, int64_t col0, int64_t ncols, void* dl, int64_t lddl,
+                             const float* rowp, void* stream);
+
+/* zero `bytes` bytes at `ptr` on `stream` (memset node; used for the fp32 accumulators of split-K GEMMs instead of a fill kernel) */
+int vacnic_zero_bytes(void* ptr, int64_t bytes, void* stream);
+
 /* ---- hardware probes (tests only): verify MFMA / ds_read_tr lane maps assumed by the kernels -- */
 int vacnic_probe_layouts(float* out, const float* src128, int64_t n_out, void* stream);
 

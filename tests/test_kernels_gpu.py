@@ -403,6 +403,47 @@ def test_cross_entropy(K, f32):
     assert (dl[:, V:] == 0).all()
 
 
+@pytest.mark.parametrize("R,V,d", [(300, 50267, 256), (64, 1000, 128), (2048, 50267, 1024)])
+def test_lmhead_ce_fused_matches_materialised_logits(K, R, V, d):
+    """lm_head + CrossEntropyLoss(ignore_index=1) without the [R, V] logits: forward statistics, every dlogits chunk and the
+    autograd Function's dh / dE against torch on materialised fp32 logits."""
+    from vacnic_amd import ops
+    Vp = (V + 31) // 32 * 32
+    h = rnd(R, d, scale=1.0, seed=1)
+    E = torch.zeros(Vp, d, device="cuda", dtype=torch.bfloat16)
+    E[:V] = rnd(V, d, scale=0.08, seed=2)
+    tgt = torch.randint(0, V, (R,), generator=torch.Generator().manual_seed(3)).cuda(); tgt[::7] = 1; tgt[5] = V - 1; tgt[6] = 0
+    hf = h.float().requires_grad_(True); Ef = E[:V].float().requires_grad_(True)
+    logits = hf @ Ef.t()
+    ref = torch.nn.functional.cross_entropy(logits, tgt, ignore_index=1)
+    ref.backward()
+    lse, acc = K.lmhead_ce_fwd(h, E, tgt, V, ignore_index=1)
+    close(lse, torch.logsumexp(logits.detach(), -1), 1e-4, 2e-3, "row lse")
+    assert acc[1].item() == (tgt != 1).sum().item()
+    assert abs((acc[0] / acc[1]).item() - ref.item()) <= 2e-3 * abs(ref.item()), ((acc[0] / acc[1]).item(), ref.item())
+    # dlogits, chunk by chunk (ragged last chunk, zero pad columns)
+    rowp = K.lmhead_ce_rowp(lse, tgt, acc, grad_out=None, grad_scale=1.0, ignore_index=1)
+    want = (torch.softmax(logits.detach(), -1) - torch.nn.functional.one_hot(tgt, V).float()) * ((tgt != 1).float() / acc[1])[:, None]
+    CH = 16384
+    dl = torch.full((R, CH), 9.0, device="cuda", dtype=torch.bfloat16)
+    for c0 in range(0, V, CH):
+        n = min(CH, V - c0); n8 = (n + 7) // 8 * 8
+        K.lmhead_ce_dlogits(h, E, tgt, V, rowp, dl, c0, n, ignore_index=1)
+        close(dl[:, :n], want[:, c0:c0 + n], 2e-2, 2e-6, f"dlogits chunk at {c0}")
+        assert (dl[:, n:n8] == 0).all(), "pad columns of a ragged chunk must be zeros"
+    # the autograd Function end to end (dh, dE accumulated into a gradient view)
+    egrad = torch.zeros(Vp, d, device="cuda")
+    hh = h.clone().requires_grad_(True)
+    anchor = torch.zeros(1, device="cuda", requires_grad=True)
+    loss, _ = ops.lm_head_ce(hh, anchor, E, egrad, tgt, V, 1)
+    assert abs(loss.item() - ref.item()) <= 2e-3 * abs(ref.item())
+    loss.backward()
+    scale = hf.grad.abs().max().item()
+    close(hh.grad, hf.grad, 3e-2, 2e-2 * scale, "dh")
+    close(egrad[:V], Ef.grad, 3e-2, 2e-2 * Ef.grad.abs().max().item(), "dE")
+    assert (egrad[V:] == 0).all()
+
+
 def test_colam(K):
     B, T, D = 6, 16, 1024
     hs = rnd(B, T, D, seed=1); hg = rnd(B, T, D, seed=2)

@@ -343,7 +343,11 @@ def test_checkpoint_resume_continues_the_run():
     meta = checkpoint.load_checkpoint(buf, model2, opt2)
     assert meta["step"] == 2 and opt2.hyper[1].item() == 2.0
     got = [train_step(model2, guide, opt2, batches[i], args).tolist() for i in range(2, 5)]
-    np.testing.assert_allclose(np.array(got), np.array(want), rtol=2e-4, atol=1e-5)
+    # first step after the restore: same weights, moments, LR position and dropout masks -> equal to fp32 atomics-order noise.
+    # Later steps: AdamW turns that noise into +-lr updates wherever a gradient is mathematically zero (e.g. k_proj.bias), and
+    # this run sits on a SECLA spike (loss 14 -> 36 -> 14), so the trajectories drift apart at the 1e-3 level run to run.
+    np.testing.assert_allclose(np.array(got[0]), np.array(want[0]), rtol=2e-5, atol=1e-5)
+    np.testing.assert_allclose(np.array(got), np.array(want), rtol=3e-3, atol=1e-4)
     assert abs(opt2.hyper[0].item() - opt.hyper[0].item()) < 1e-12
 
 

@@ -101,6 +101,10 @@ NameEmbedArgs = _struct("vacnic_name_embed_args", [
     ("B", i64), ("Nn", i64), ("Ln", i64), ("D", i64), ("V", i64), ("pos_offset", i64),
     ("embed_scale", f32), ("eps", f32)])
 
+LmheadCeArgs = _struct("vacnic_lmhead_ce_args", [
+    ("h", vp), ("emb", vp), ("bias", vp), ("targets", vp), ("part", vp), ("tl", vp), ("row_lse", vp), ("loss_sum", vp), ("count", vp),
+    ("R", i64), ("V", i64), ("D", i64), ("ldh", i64), ("lde", i64), ("part_tiles", i64), ("ignore_index", i64)])
+
 AdamwArgs = _struct("vacnic_adamw_args", [
     ("p", vp), ("g", vp), ("m", vp), ("v", vp), ("p_bf16", vp), ("hyper", vp),
     ("n", i64), ("beta1", f32), ("beta2", f32), ("eps", f32), ("weight_decay", f32), ("grad_scale", f32),
@@ -115,7 +119,7 @@ _STRUCT_FNS = {
     "vacnic_ce_fwd": CeArgs, "vacnic_ce_bwd": CeArgs,
     "vacnic_colam_fwd": ColamFwdArgs, "vacnic_colam_bwd": ColamBwdArgs,
     "vacnic_secla_fwd": SeclaFwdArgs, "vacnic_secla_bwd": SeclaBwdArgs,
-    "vacnic_name_embed_mean": NameEmbedArgs, "vacnic_adamw": AdamwArgs,
+    "vacnic_name_embed_mean": NameEmbedArgs, "vacnic_adamw": AdamwArgs, "vacnic_lmhead_ce_fwd": LmheadCeArgs,
 }
 _PLAIN_FNS = {
     "vacnic_combine_losses": [vp, vp, vp, vp, f32, f32, vp, vp],
@@ -137,6 +141,9 @@ _PLAIN_FNS = {
     "vacnic_beam_topk": [vp, vp, vp, i32, i32, i32, i32, vp, vp, i64, i64, i64, i32, i32, vp],
     "vacnic_gather_rows": [vp, vp, vp, i64, i64, vp],
     "vacnic_image_u8_normalize": [vp, vp, vp, i64, i64, i64, f32, f32, f32, f32, f32, f32, vp],
+    "vacnic_lmhead_ce_rowp": [vp, vp, vp, vp, f32, vp, i64, i64, vp],
+    "vacnic_lmhead_ce_dlogits": [C.POINTER(LmheadCeArgs), i64, i64, vp, i64, vp, vp],
+    "vacnic_zero_bytes": [vp, i64, vp],
 }
 EXPORTED = sorted(list(_STRUCT_FNS) + list(_PLAIN_FNS) + ["vacnic_last_error_string", "vacnic_version"])
 

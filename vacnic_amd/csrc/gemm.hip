@@ -127,7 +127,7 @@ static double cfg_cost(const TileCfg& c, int64_t M, int64_t N, int64_t kper, int
   return (double)rounds * ((double)c.per_cu * c.bm * c.bn * (double)kper / c.eff + kFixedUnits);
 }
 
-static int gemm_one(const vacnic_gemm_args* a, int hint, void* stream);
+static int gemm_one(const vacnic_gemm_args* a, int hint, void* stream, int ce_mode = 0, int ce_col0 = 0);
 
 extern "C" int vacnic_gemm_bf16(const vacnic_gemm_args* a, void* stream) {
   VCHECK(a && a->x && a->w && a->out, VACNIC_BAD_SHAPE, "gemm: null operand");
@@ -173,7 +173,7 @@ extern "C" int vacnic_gemm_bf16(const vacnic_gemm_args* a, void* stream) {
   return gemm_one(&tail_a, kCfgs[2].hint, stream);
 }
 
-static int gemm_one(const vacnic_gemm_args* a, int tile_hint, void* stream) {
+static int gemm_one(const vacnic_gemm_args* a, int tile_hint, void* stream, int ce_mode, int ce_col0) {
   VCHECK((a->ldx & 7) == 0 && (a->ldw & 7) == 0, VACNIC_MISALIGNED, "gemm: ldx/ldw must be multiples of 8");
   VCHECK(aligned16(a->x) && aligned16(a->w), VACNIC_MISALIGNED, "gemm: x/w must be 16-byte aligned");
   VCHECK(a->out_mode >= 0 && a->out_mode <= 2, VACNIC_BAD_DTYPE, "gemm: bad out_mode %d", a->out_mode);
@@ -199,7 +199,8 @@ static int gemm_one(const vacnic_gemm_args* a, int tile_hint, void* stream) {
   p.xsum = a->xsum;
   p.M = (int)a->M; p.N = (int)a->N; p.K = (int)a->K;
   p.ldx = (int)a->ldx; p.ldw = (int)a->ldw; p.ldo = (int)a->ldo;
-  p.act = a->act; p.out_mode = a->out_mode; p.split_k = split;
+  p.act = a->act; p.out_mode = ce_mode ? ce_mode : a->out_mode; p.split_k = split;
+  p.ce_col0 = ce_col0;
   int kps = (int)((a->K + split - 1) / split);
   kps = (kps + BK - 1) / BK * BK;               // multiple of 64: valid for both K-tile depths
   p.k_per_split = kps;
@@ -231,6 +232,7 @@ static int gemm_one(const vacnic_gemm_args* a, int tile_hint, void* stream) {
   // the bf16 epilogue addresses its outputs through 32-bit buffer offsets: larger outputs take the fp32-staged path
   if (((a->M - 1) * a->ldo + a->N) * 2 >= 0x7ffffff0LL) p.debug |= 16;
   if ((a->preact != nullptr) + (a->dact_src != nullptr) + (a->residual != nullptr) > 1) p.debug |= 16;   // bf16 epilogue: one extra operand
+  if (ce_mode) p.debug |= 16;
   const bool big = force == 256;
   const bool mid = force == 128;
   // A/B baselines kept for the ablations in profiles/: plain K loops and the 64-wide software-pipelined loop
@@ -241,4 +243,113 @@ static int gemm_one(const vacnic_gemm_args* a, int tile_hint, void* stream) {
   if (big) return launch_t256(p, a->x_kstrided, a->w_kstrided, zsplits, s);   // ping-pong loop
   if (mid) return launch_t128(p, a->x_kstrided, a->w_kstrided, zsplits, s);
   return launch_t64(p, a->x_kstrided, a->w_kstrided, zsplits, s);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused LM head + cross entropy (MFULL:1885,1997 lm_head; TRAIN:287,816 CrossEntropyLoss(ignore_index=pad)): the
+// [R, V] logits are never written.  Forward = one GEMM whose epilogue reduces every 256-column tile of a row to an
+// online-softmax pair and picks the target's logit, plus a small combine; backward recomputes the logits one vocabulary
+// chunk at a time straight into bf16 dlogits (vacnic_lmhead_ce_dlogits), which the caller feeds to the dh / dE GEMMs.
+namespace {
+__global__ __launch_bounds__(256) void ce_combine_kernel(const float* __restrict__ part, const float* __restrict__ tl,
+                                                          const int64_t* __restrict__ targets, float* __restrict__ row_lse,
+                                                          float* __restrict__ loss_sum, float* __restrict__ count, int R, int tiles,
+                                                          int64_t ignore) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = blockIdx.x * 4 + wave;
+  float loss = 0.f, cnt = 0.f;
+  if (r < R) {
+    float mx = -INFINITY, sm = 0.f;
+    for (int t = lane; t < tiles; t += 64) {
+      const float pm = part[((size_t)r * tiles + t) * 2], ps = part[((size_t)r * tiles + t) * 2 + 1];
+      if (pm > -INFINITY) {
+        const float nm = fmaxf(mx, pm);
+        sm = (mx == -INFINITY ? 0.f : sm * __expf(mx - nm)) + ps * __expf(pm - nm);
+        mx = nm;
+      }
+    }
+    const float gm = wave_max(mx);
+    const float gs = wave_sum(mx == -INFINITY ? 0.f : sm * __expf(mx - gm));
+    const float lse = gm + __logf(gs);
+    if (lane == 0) {
+      row_lse[r] = lse;
+      if (targets[r] != ignore) { loss = lse - tl[r]; cnt = 1.f; }
+    }
+  }
+  __shared__ float red[2][4];
+  if (lane == 0) { red[0][wave] = loss; red[1][wave] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float l = red[0][0] + red[0][1] + red[0][2] + red[0][3], c = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    if (c > 0.f) { atomicAdd(loss_sum, l); atomicAdd(count, c); }
+  }
+}
+
+__global__ void ce_rowp_kernel(const float* __restrict__ row_lse, const int64_t* __restrict__ targets, const float* __restrict__ count,
+                               const float* __restrict__ grad_out, float grad_scale, float* __restrict__ rowp, int R, int64_t ignore) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const float c = fmaxf(*count, 1.f);
+  const float g = (grad_out ? *grad_out : 1.f) * grad_scale / c;
+  rowp[2 * r] = row_lse[r];
+  rowp[2 * r + 1] = targets[r] != ignore ? g : 0.f;
+}
+}  // namespace
+
+static void fill_lmhead_gemm(vacnic_gemm_args& g, const vacnic_lmhead_ce_args* a, const void* emb, int64_t N) {
+  g = vacnic_gemm_args{};
+  g.x = a->h; g.w = emb; g.bias = a->bias;
+  g.M = a->R; g.N = N; g.K = a->D;
+  g.ldx = a->ldh; g.ldw = a->lde;
+  g.alpha = 1.0f; g.split_k = 1;
+}
+
+extern "C" int vacnic_lmhead_ce_fwd(const vacnic_lmhead_ce_args* a, void* stream) {
+  VCHECK(a && a->h && a->emb && a->targets && a->part && a->tl && a->row_lse && a->loss_sum && a->count, VACNIC_BAD_SHAPE,
+         "lmhead_ce_fwd: null operand");
+  VCHECK(a->R > 0 && a->V > 0 && a->D > 0, VACNIC_BAD_SHAPE, "lmhead_ce_fwd: empty problem");
+  const int64_t tiles = (a->V + 255) / 256;
+  VCHECK(a->part_tiles >= tiles, VACNIC_BAD_SHAPE, "lmhead_ce_fwd: part holds %ld tiles per row, %ld needed", (long)a->part_tiles, (long)tiles);
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(a->loss_sum, 0, sizeof(float), st) != hipSuccess || hipMemsetAsync(a->count, 0, sizeof(float), st) != hipSuccess) {
+    vacnic_set_error("lmhead_ce_fwd: memset failed");
+    return VACNIC_HIP_ERROR;
+  }
+  vacnic_gemm_args g;
+  fill_lmhead_gemm(g, a, a->emb, a->V);
+  g.out = a->part;                       // never written through `out`; the epilogue uses preact / xsum / dact_src
+  g.ldo = a->V;
+  g.preact = a->part; g.xsum = a->tl; g.dact_src = a->targets;
+  if (a->part_tiles != tiles) {          // the kernel indexes part[m][tiles_n] with ITS tile count
+    vacnic_set_error("lmhead_ce_fwd: part_tiles must equal ceil(V / 256) = %ld", (long)tiles);
+    return VACNIC_BAD_SHAPE;
+  }
+  if (int e = gemm_one(&g, 256 + 64000, stream, 3, 0)) return e;
+  hipLaunchKernelGGL(ce_combine_kernel, dim3((unsigned)((a->R + 3) / 4)), dim3(256), 0, st, a->part, a->tl, a->targets, a->row_lse,
+                     a->loss_sum, a->count, (int)a->R, (int)tiles, a->ignore_index);
+  VLAUNCH_CHECK();
+  return VACNIC_OK;
+}
+
+extern "C" int vacnic_lmhead_ce_rowp(const float* row_lse, const int64_t* targets, const float* count, const float* grad_out,
+                                     float grad_scale, float* rowp, int64_t R, int64_t ignore_index, void* stream) {
+  VCHECK(row_lse && targets && count && rowp && R > 0, VACNIC_BAD_SHAPE, "lmhead_ce_rowp: bad operand");
+  hipLaunchKernelGGL(ce_rowp_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, (hipStream_t)stream, row_lse, targets, count,
+                     grad_out, grad_scale, rowp, (int)R, ignore_index);
+  VLAUNCH_CHECK();
+  return VACNIC_OK;
+}
+
+extern "C" int vacnic_lmhead_ce_dlogits(const vacnic_lmhead_ce_args* a, int64_t col0, int64_t ncols, void* dl, int64_t lddl,
+                                        const float* rowp, void* stream) {
+  VCHECK(a && a->h && a->emb && a->targets && dl && rowp, VACNIC_BAD_SHAPE, "lmhead_ce_dlogits: null operand");
+  VCHECK(col0 >= 0 && ncols > 0 && col0 + ncols <= a->V, VACNIC_BAD_SHAPE, "lmhead_ce_dlogits: chunk [%ld, +%ld) outside V=%ld",
+         (long)col0, (long)ncols, (long)a->V);
+  VCHECK((lddl & 7) == 0 && lddl >= ((ncols + 7) & ~7LL) && aligned16(dl), VACNIC_MISALIGNED, "lmhead_ce_dlogits: dl rows must be 16-byte aligned and hold round_up(ncols, 8)");
+  vacnic_gemm_args g;
+  fill_lmhead_gemm(g, a, (const char*)a->emb + col0 * a->lde * 2, ncols);
+  if (g.bias) g.bias = a->bias + col0;
+  g.out = dl; g.ldo = lddl;
+  g.dact_src = a->targets; g.residual = rowp;
+  return gemm_one(&g, 256 + 64000, stream, 4, (int)col0);
 }

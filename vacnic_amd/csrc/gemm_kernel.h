@@ -21,6 +21,7 @@ struct GemmP {
   float alpha;
   unsigned x_bytes, w_bytes;
   int tiles_m, tiles_n;
+  int ce_col0;          // out_mode 3 / 4: global vocabulary index of this launch's column 0 (targets are global ids)
   int debug;            // profiling aid (tile_hint >= 1000): bit0 skip the global stores, bit1 skip the K loop, bit2 skip the epilogue, bit3 return at once, bit4 fp32 staged epilogue, bit5 no LDS-DMA in the loop, bit6 one workgroup per tile (not persistent), bit7 no fragment reads
 };
 
@@ -793,6 +794,70 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
       }
     }
     __syncthreads();
+    if (q.out_mode >= 3) {
+      // ---- fused LM-head cross-entropy epilogues (MFULL:1997 + TRAIN:287): the logits tile never leaves the chip.
+      //   out_mode 3 (forward): per row of this tile, the online-softmax pair {max, sum exp(. - max)} over the tile's valid
+      //                columns -> ce_part[m][tn]; the target column's logit -> ce_tl[m] (by the one tile that holds it)
+      //   out_mode 4 (backward, logits recomputed): dlogit = (exp(logit - lse[m]) - [n == target[m]]) * coef[m] -> bf16 out
+      // (targets: q.dact_src as int64; forward: part = q.preact, tl = q.xsum; backward: {lse, coef} pairs = q.residual.)
+      constexpr int TPR = NTHR / 64, CPT = BN / TPR;          // threads per staged row, columns per thread
+      static_assert(CPT % 8 == 0, "column groups of 8");
+      const int row = te / TPR, seg = te % TPR;
+      const int m = m0 + tile_row(pass, row);
+      const bool mok = m < q.M;
+      const int nb = n0 + seg * CPT;
+      const float* src = sc + row * CLD + seg * CPT;
+      const long long tgt = mok ? ((const long long*)q.dact_src)[m] - p.ce_col0 : -1;      // column inside this launch's N range
+      if (q.out_mode == 3) {
+        float mx = -INFINITY, sm = 0.f;
+#pragma unroll
+        for (int j0 = 0; j0 < CPT; j0 += 4) {
+          const f32x4 v4 = *(const f32x4*)(src + j0);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int n = nb + j0 + j;
+            if (n < q.N) {
+              float v = v4[j] * q.alpha;
+              if (q.bias) v += q.bias[n];
+              if (n == tgt) q.xsum[m] = v;
+              const float nm = fmaxf(mx, v);
+              sm = sm * __expf(mx - nm) + __expf(v - nm);
+              mx = nm;
+            }
+          }
+        }
+#pragma unroll
+        for (int o = 1; o < TPR; o <<= 1) {
+          const float omx = __shfl_xor(mx, o, 64), osm = __shfl_xor(sm, o, 64);
+          const float nm = fmaxf(mx, omx);
+          sm = (mx == -INFINITY ? 0.f : sm * __expf(mx - nm)) + (omx == -INFINITY ? 0.f : osm * __expf(omx - nm));
+          mx = nm;
+        }
+        if (seg == 0 && mok) {
+          float* part = (float*)q.preact + ((size_t)m * p.tiles_n + tn) * 2;
+          part[0] = mx; part[1] = sm;
+        }
+      } else if (mok) {
+        const float lse = ((const float*)q.residual)[2 * m], coef = ((const float*)q.residual)[2 * m + 1];
+        bf16_t* orow = (bf16_t*)q.out + (size_t)m * q.ldo;
+#pragma unroll
+        for (int j0 = 0; j0 < CPT; j0 += 8) {
+          const int n = nb + j0;
+          if (n >= ((q.N + 7) & ~7)) continue;
+          const f32x4 a4 = *(const f32x4*)(src + j0), b4 = *(const f32x4*)(src + j0 + 4);
+          float d[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float v = (j < 4 ? a4[j & 3] : b4[j & 3]) * q.alpha;
+            if (q.bias && n + j < q.N) v += q.bias[n + j];
+            d[j] = n + j < q.N ? (__expf(v - lse) - (n + j == tgt ? 1.f : 0.f)) * coef : 0.f;     // pad columns: exact zeros
+          }
+          store8bf(orow + n, d);                            // ldo % 8 == 0 and 16-byte rows are checked on the host
+        }
+      }
+      __syncthreads();
+      continue;
+    }
     if (q.out_mode == 2 && q.split_k > 1) {
       // split-K accumulate: f32 atomics shaped as 256 contiguous bytes per wve-instruction (one row, 64
       // consecutive columns) — the shape the memory-side atomic units run at full rate on

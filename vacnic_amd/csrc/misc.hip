@@ -304,3 +304,14 @@ extern "C" int vacnic_image_u8_normalize(const uint8_t* src, const uint8_t* flip
   VLAUNCH_CHECK();
   return VACNIC_OK;
 }
+
+// zero-fill on the caller's stream (a memset node: graph-capturable, no kernel) — the fp32 accumulators of split-K GEMMs
+extern "C" int vacnic_zero_bytes(void* ptr, int64_t bytes, void* stream) {
+  VCHECK(ptr && bytes >= 0, VACNIC_BAD_SHAPE, "zero_bytes: bad operand");
+  if (bytes == 0) return VACNIC_OK;
+  if (hipMemsetAsync(ptr, 0, (size_t)bytes, (hipStream_t)stream) != hipSuccess) {
+    vacnic_set_error("zero_bytes: hipMemsetAsync failed");
+    return VACNIC_HIP_ERROR;
+  }
+  return VACNIC_OK;
+}

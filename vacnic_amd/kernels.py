@@ -227,6 +227,47 @@ def ce_bwd(logits, targets, V, row_lse, acc, dlogits, grad_out=None, grad_scale=
                 ignore_index=ignore_index, logits_f32=int(logits.dtype == torch.float32))
 
 
+def zero_(t):
+    """t.zero_() as a memset node on the launch stream (no fill kernel)."""
+    assert t.is_contiguous()
+    call("vacnic_zero_bytes", _p(t), t.numel() * t.element_size(), _stream())
+    return t
+
+
+def _lmhead_args(h2, emb16, targets, V, ignore_index, part=None, tl=None, row_lse=None, acc=None):
+    R, D = h2.shape
+    return _lib.LmheadCeArgs(h=_p(h2), emb=_p(emb16), bias=None, targets=_p(targets), part=_p(part), tl=_p(tl), row_lse=_p(row_lse),
+                             loss_sum=acc.data_ptr() if acc is not None else None, count=acc.data_ptr() + 4 if acc is not None else None,
+                             R=R, V=V, D=D, ldh=h2.stride(0), lde=emb16.stride(0), part_tiles=(V + 255) // 256, ignore_index=ignore_index)
+
+
+def lmhead_ce_fwd(h2, emb16, targets, V, ignore_index=1):
+    """fused lm_head + CrossEntropyLoss forward without logits: returns (row_lse [R], acc = {loss_sum, count})."""
+    R = h2.shape[0]
+    dev = h2.device
+    tiles = (V + 255) // 256
+    part = torch.empty((R, tiles, 2), device=dev, dtype=torch.float32)
+    tl = torch.empty(R, device=dev, dtype=torch.float32)
+    row_lse = torch.empty(R, device=dev, dtype=torch.float32)
+    acc = torch.empty(2, device=dev, dtype=torch.float32)
+    st = _lmhead_args(h2, emb16, targets, V, ignore_index, part, tl, row_lse, acc)
+    _lib.check(_lib.lib.vacnic_lmhead_ce_fwd(_lib.C.byref(st), _stream()))
+    return row_lse, acc
+
+
+def lmhead_ce_rowp(row_lse, targets, acc, grad_out=None, grad_scale=1.0, ignore_index=1):
+    R = row_lse.shape[0]
+    rowp = torch.empty((R, 2), device=row_lse.device, dtype=torch.float32)
+    call("vacnic_lmhead_ce_rowp", _p(row_lse), _p(targets), acc.data_ptr() + 4, _p(grad_out), grad_scale, _p(rowp), R, ignore_index, _stream())
+    return rowp
+
+
+def lmhead_ce_dlogits(h2, emb16, targets, V, rowp, dl, col0, ncols, ignore_index=1):
+    """dl[:, :round_up(ncols, 8)] = bf16 dlogits of vocabulary columns [col0, col0 + ncols) (logits recomputed on chip)."""
+    st = _lmhead_args(h2, emb16, targets, V, ignore_index)
+    _lib.check(_lib.lib.vacnic_lmhead_ce_dlogits(_lib.C.byref(st), col0, ncols, _p(dl), dl.stride(0), _p(rowp), _stream()))
+
+
 def combine_losses(ce_sum_ptr, count_ptr, secla, colam, w_secla, w_colam, device):
     out4 = torch.empty(4, device=device, dtype=torch.float32)
     call("vacnic_combine_losses", ce_sum_ptr, count_ptr, _p(secla), _p(colam), w_secla, w_colam, out4.data_ptr(), _stream())

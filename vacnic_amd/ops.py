@@ -430,48 +430,49 @@ def to_bf16(x):
 
 
 # ---------------------------------------------------------------------------------------------- losses
+LMHEAD_CHUNK = 16384        # vocabulary columns of dlogits alive at a time in the backward ([R, 16384] bf16 = 64 MiB at R = 2048)
+
+
 class LmHeadCeFn(Function):
-    """lm_head (tied to shared, MFULL:1885,1997) + CrossEntropyLoss(ignore_index=pad) (TRAIN:287).
-    Logits are materialised once in fp32 [R, V_pad]; backward overwrites a bf16 buffer with dlogits and
-    runs the two GEMMs (dh, dE)."""
+    """lm_head (tied to shared, MFULL:1885,1997) + CrossEntropyLoss(ignore_index=pad) (TRAIN:287) WITHOUT the [R, V] logits
+    (SURVEY §8a row a8).  Forward: one GEMM whose epilogue keeps, per 256-column tile and row, the online-softmax pair and
+    the target logit (3 MB instead of 412 MB of fp32 logits) + a combine kernel.  Backward: the logits are recomputed one
+    vocabulary chunk at a time directly as bf16 dlogits, each chunk feeding the dh (split-K, fp32 accumulate) and dE
+    (into the tied matrix's gradient rows) GEMMs before the buffer is re-used."""
 
     @staticmethod
     def forward(ctx, h, anchor, emb16_pad, egrad, targets, V, ignore_index, ge):
         d = h.shape[-1]
         h2 = _c(h).view(-1, d)
-        R = h2.shape[0]
-        Vp = emb16_pad.shape[0]
-        logits = torch.empty((R, Vp), device=h.device, dtype=torch.float32)
-        K.gemm(h2, emb16_pad, R, V, d, out=logits, ldo=Vp, out_mode=1)
         tgt = _c(targets).view(-1)
-        row_lse, acc = K.ce_fwd(logits, tgt, V, ignore_index=ignore_index)
+        row_lse, acc = K.lmhead_ce_fwd(h2, emb16_pad, tgt, V, ignore_index=ignore_index)
         out4 = K.combine_losses(acc.data_ptr(), acc.data_ptr() + 4, None, None, 0.0, 0.0, h.device)
-        ctx.misc = (emb16_pad, egrad, V, ignore_index, R, d, h.shape)
-        ctx.save_for_backward(h2, logits, tgt, row_lse, acc)
+        ctx.misc = (emb16_pad, egrad, V, ignore_index, h2.shape[0], d, h.shape)
+        ctx.save_for_backward(h2, tgt, row_lse, acc)
         ctx.mark_non_differentiable(acc)
         ddp.expect(ge and any(ctx.needs_input_grad), egrad)
         return out4[1], acc
 
     @staticmethod
     def backward(ctx, g, _gacc):
-        h2, logits, tgt, row_lse, acc = ctx.saved_tensors
+        h2, tgt, row_lse, acc = ctx.saved_tensors
         emb16_pad, egrad, V, ignore_index, R, d, hshape = ctx.misc
-        Vp = emb16_pad.shape[0]
-        dl = torch.empty((R, Vp), device=h2.device, dtype=BF16)
-        K.ce_bwd(logits, tgt, V, row_lse, acc, dl, grad_out=_c(g), grad_scale=1.0, ignore_index=ignore_index)
-        dh = torch.empty((R, d), device=h2.device, dtype=BF16)
-        if Vp >= 8 * max(R, d) and R * d <= (1 << 23):
-            # dh = dlogits . E with a reduction 25-50x longer than the output is wide (R x d = 2048 x 1024, K = 50272): as one
-            # launch it is 32 tiles of 256x256 on 256 CUs (726 us); split-K over 8 slices accumulated in fp32, then one cast
-            dh32 = torch.zeros((R, d), device=h2.device, dtype=torch.float32)
-            K.gemm(dl, emb16_pad, R, d, Vp, out=dh32, w_kstrided=True, out_mode=2, split_k=8)
-            K.cast_f32_bf16(dh32, dh)
-        else:
-            K.gemm(dl, emb16_pad, R, d, Vp, out=dh, w_kstrided=True)      # dh = dlogits . E   (pad rows of E are zero)
-        if egrad is not None:                                               # dE[V,d] += dlogits^T h
-            tiles = ((V + 127) // 128) * ((d + 127) // 128)
-            K.gemm(dl, h2, V, d, R, out=egrad, ldx=Vp, ldw=d, ldo=d, x_kstrided=True, w_kstrided=True, out_mode=2,
-                   split_k=K.wgrad_split(R, tiles))
+        rowp = K.lmhead_ce_rowp(row_lse, tgt, acc, grad_out=_c(g), grad_scale=1.0, ignore_index=ignore_index)
+        CH = min(LMHEAD_CHUNK, (V + 7) // 8 * 8)
+        dl = torch.empty((R, CH), device=h2.device, dtype=BF16)
+        dh32 = K.zero_(torch.empty((R, d), device=h2.device, dtype=torch.float32))
+        for c0 in range(0, V, CH):
+            n = min(CH, V - c0)
+            n8 = (n + 7) // 8 * 8                                  # dlogits pad columns are written as zeros; E's pad rows are zero
+            K.lmhead_ce_dlogits(h2, emb16_pad, tgt, V, rowp, dl, c0, n, ignore_index=ignore_index)
+            ec = emb16_pad[c0:c0 + n8]
+            # dh += dlogits_c . E_c: a reduction 8-16x longer than the output is wide -> split-K, fp32 accumulate
+            K.gemm(dl, ec, R, d, n8, out=dh32, ldx=CH, w_kstrided=True, out_mode=2, split_k=8)
+            if egrad is not None:                                  # dE[c0:c0+n] += dlogits_c^T h
+                tiles = ((n + 127) // 128) * ((d + 127) // 128)
+                K.gemm(dl, h2, n, d, R, out=egrad[c0:c0 + n], ldx=CH, ldw=d, ldo=d, x_kstrided=True, w_kstrided=True, out_mode=2,
+                       split_k=K.wgrad_split(R, tiles))
+        dh = K.cast_f32_bf16(dh32)
         ddp.done(egrad)
         return dh.view(hshape), None, None, None, None, None, None, None
 
