@@ -364,6 +364,13 @@ def copy3d(src, dst, B, rows, cols, accumulate=False):
          int(accumulate), _stream())
 
 
+def zero_strided(t):
+    """zero a [B, rows, cols] bf16 view with unit inner stride (rare fallback: an unused slot of a batched gradient buffer)."""
+    z = torch.empty((t.shape[0], t.shape[1], t.shape[2]), device=t.device, dtype=t.dtype)
+    zero_(z)
+    copy3d(z, t, t.shape[0], t.shape[1], t.shape[2])
+
+
 def cat_tokens(parts):
     """torch.cat(parts, dim=1) for [B, T_i, D] bf16 tensors (MFULL:666,691)."""
     B, _, D = parts[0].shape

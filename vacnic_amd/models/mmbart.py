@@ -84,8 +84,11 @@ class BartAttention(nn.Module):
     out_proj output; the additive [B,1,T,S] mask of the reference is replaced by its generator: a per-key
     uint8 mask (0 = masked with finfo.min) and a causal flag."""
 
-    def __init__(self, embed_dim, num_heads, dropout=0.0, is_decoder=False, bias=True):
+    def __init__(self, embed_dim, num_heads, dropout=0.0, is_decoder=False, bias=True, cross_only=False):
+        """cross_only: an attention that is only ever used with key_value_states (the decoder's encoder_attn): its k|v
+        parameters are laid out by the owner (BartDecoder batches all layers' k|v into one arena group), q separately."""
         super().__init__()
+        self.cross_only = cross_only
         self.embed_dim, self.num_heads, self.dropout = embed_dim, num_heads, dropout
         self.head_dim = embed_dim // num_heads
         if self.head_dim * num_heads != embed_dim:
@@ -102,13 +105,16 @@ class BartAttention(nn.Module):
         self.out_proj = nn.Linear(embed_dim, embed_dim, bias=bias)
 
     def arena_groups(self):
+        if self.cross_only:
+            return [[self.k_proj.weight, self.v_proj.weight], [self.k_proj.bias, self.v_proj.bias]]
         return [[self.k_proj.weight, self.v_proj.weight, self.q_proj.weight], [self.k_proj.bias, self.v_proj.bias, self.q_proj.bias]]
 
     def bind_arena(self, a):
         ws = [self.k_proj.weight, self.v_proj.weight, self.q_proj.weight]
         bs = [self.k_proj.bias, self.v_proj.bias, self.q_proj.bias]
         t = a.trainable
-        self.s_kvq = LinearSpec(a.fused(ws, "w16"), a.fused(bs, "f32"), a.fused(ws, "grad") if t else None, a.fused(bs, "grad") if t else None)
+        if not self.cross_only:
+            self.s_kvq = LinearSpec(a.fused(ws, "w16"), a.fused(bs, "f32"), a.fused(ws, "grad") if t else None, a.fused(bs, "grad") if t else None)
         self.s_kv = LinearSpec(a.fused(ws[:2], "w16"), a.fused(bs[:2], "f32"), a.fused(ws[:2], "grad") if t else None, a.fused(bs[:2], "grad") if t else None)
         self.s_q = _spec(self.q_proj, t)
         self.s_out = _spec(self.out_proj, t)
@@ -117,18 +123,26 @@ class BartAttention(nn.Module):
         """fused k|v projection of a cross-attention source (MFULL:478-484)."""
         return ops.linear(key_value_states, self.k_proj.weight, self.s_kv)
 
-    def forward(self, hidden_states, key_value_states=None, key_mask=None, causal=False, kv=None):
-        """kv: optional precomputed project_kv(key_value_states)."""
+    def forward(self, hidden_states, key_value_states=None, key_mask=None, causal=False, kv=None, skip=False, bank=None, slot=0):
+        """kv: optional precomputed project_kv(key_value_states).  skip=True: returns (output, hidden_states) — the residual
+        branch of the block, whose gradient joins the input gradient inside the first projection's dgrad GEMM."""
         H = self.num_heads
+        lin = ops.linear_skip if skip else ops.linear
+        res = None
         if key_value_states is None and kv is None:
-            kvq = ops.linear(hidden_states, self.k_proj.weight, self.s_kvq)
+            kvq = lin(hidden_states, self.k_proj.weight, self.s_kvq)
+            if skip:
+                kvq, res = kvq
             ctx = ops.self_attention(kvq, key_mask, causal, H)
         else:
-            q = ops.linear(hidden_states, self.q_proj.weight, self.s_q)
+            q = lin(hidden_states, self.q_proj.weight, self.s_q)
+            if skip:
+                q, res = q
             if kv is None:
                 kv = self.project_kv(key_value_states)
-            ctx = ops.cross_attention(q, kv, key_mask, H)
-        return ops.linear(ctx, self.out_proj.weight, self.s_out)
+            ctx = ops.cross_attention(q, kv, key_mask, H, bank, slot)
+        out = ops.linear(ctx, self.out_proj.weight, self.s_out)
+        return (out, res) if skip else out
 
 
 class _Ffn(nn.Module):
@@ -192,8 +206,8 @@ class BartEncoderLayer(nn.Module):
                 br.wait_stream(cur)
             with (torch.cuda.stream(br) if br is not None else contextlib.nullcontext()):
                 # img FFN (MFULL:647-653)
-                a, r = ops.fork(hidden_states_img)
-                hidden_states_img = self._ln(ops.mlp2(a, self.fc1.weight, self.s_up, self.s_down), r, self.img_layer_norm)
+                a, r = ops.mlp2_skip(hidden_states_img, self.fc1.weight, self.s_up, self.s_down)
+                hidden_states_img = self._ln(a, r, self.img_layer_norm)
                 if not self.only_image:
                     if not add_ner_ffn:
                         # MFULL:665-666 concatenates [img ; names ; text] as keys while the mask of MFULL:1293-1296 covers
@@ -205,8 +219,8 @@ class BartEncoderLayer(nn.Module):
                         raise ValueError(f"Attention mask should be of size {(Bq, 1, Sq, n_kv)}, but is "
                                          f"torch.Size([{Bq}, 1, {Sq}, {n_mask}])")
                     # face FFN (:658-664)
-                    a, r = ops.fork(hidden_states_face)
-                    hidden_states_face = self._ln(ops.mlp2(a, self.fc1.weight, self.s_fup, self.s_fdown), r, self.face_layer_norm)
+                    a, r = ops.mlp2_skip(hidden_states_face, self.fc1.weight, self.s_fup, self.s_fdown)
+                    hidden_states_face = self._ln(a, r, self.face_layer_norm)
                     face_kv, face_out = ops.fork(hidden_states_face)
                     # names attend to [faces ; names] (:666-679) — no dropout on this branch in the reference
                     ner_q, ner_r = ops.fork(hidden_states_ner)
@@ -226,17 +240,17 @@ class BartEncoderLayer(nn.Module):
                 else:
                     kv, hidden_states_img = ops.fork(hidden_states_img)
                 kv = self.cross_attn_img_ner.project_kv(kv)        # k|v projection of the [img ; prefix] tokens: also off the text chain
-            a, r = ops.fork(h)
-            h = self._ln(self.self_attn(a, key_mask=key_mask), r, self.self_attn_layer_norm)      # :697-707
+            a, r = self.self_attn(h, key_mask=key_mask, skip=True)
+            h = self._ln(a, r, self.self_attn_layer_norm)                                          # :697-707
             if br is not None:
                 cur.wait_stream(br)
-            a, r = ops.fork(h)
-            h = self._ln(self.cross_attn_img_ner(a, kv=kv, key_mask=None), r, self.img_ner_attn_layer_norm)   # :711-723
+            a, r = self.cross_attn_img_ner(h, kv=kv, key_mask=None, skip=True)
+            h = self._ln(a, r, self.img_ner_attn_layer_norm)                                       # :711-723
         else:
-            a, r = ops.fork(h)
-            h = self._ln(self.self_attn(a, key_mask=key_mask), r, self.self_attn_layer_norm)      # :726-736
-        a, r = ops.fork(h)
-        h = self._ln(ops.mlp2(a, self.fc1.weight, self.s_fc1, self.s_fc2), r, self.final_layer_norm)   # :738-744
+            a, r = self.self_attn(h, key_mask=key_mask, skip=True)
+            h = self._ln(a, r, self.self_attn_layer_norm)                                          # :726-736
+        a, r = ops.mlp2_skip(h, self.fc1.weight, self.s_fc1, self.s_fc2)
+        h = self._ln(a, r, self.final_layer_norm)                                                  # :738-744
         return h, hidden_states_face, hidden_states_ner, hidden_states_img
 
 
@@ -249,7 +263,7 @@ class BartDecoderLayer(nn.Module):
         self.self_attn = BartAttention(d, config.decoder_attention_heads, dropout=config.attention_dropout, is_decoder=True)
         self.dropout = config.dropout
         self.self_attn_layer_norm = nn.LayerNorm(d)
-        self.encoder_attn = BartAttention(d, config.decoder_attention_heads, dropout=config.attention_dropout, is_decoder=True)
+        self.encoder_attn = BartAttention(d, config.decoder_attention_heads, dropout=config.attention_dropout, is_decoder=True, cross_only=True)
         self.encoder_attn_layer_norm = nn.LayerNorm(d)
         self.fc1 = nn.Linear(d, config.decoder_ffn_dim)
         self.fc2 = nn.Linear(config.decoder_ffn_dim, d)
@@ -261,14 +275,13 @@ class BartDecoderLayer(nn.Module):
     def _ln(self, x, res, ln):
         return ops.add_ln(x, res, ln.weight, ln.bias, self.dropout, self.training)
 
-    def forward(self, hidden_states, encoder_hidden_states, encoder_key_mask):
-        a, r = ops.fork(hidden_states)
-        h = self._ln(self.self_attn(a, causal=hidden_states.shape[1] > 1), r, self.self_attn_layer_norm)
-        a, r = ops.fork(h)
-        h = self._ln(self.encoder_attn(a, key_value_states=encoder_hidden_states, key_mask=encoder_key_mask), r,
-                     self.encoder_attn_layer_norm)
-        a, r = ops.fork(h)
-        return self._ln(ops.mlp2(a, self.fc1.weight, self.s_fc1, self.s_fc2), r, self.final_layer_norm)
+    def forward(self, hidden_states, encoder_hidden_states, encoder_key_mask, kv=None, bank=None, slot=0):
+        a, r = self.self_attn(hidden_states, causal=hidden_states.shape[1] > 1, skip=True)
+        h = self._ln(a, r, self.self_attn_layer_norm)
+        a, r = self.encoder_attn(h, key_value_states=encoder_hidden_states, key_mask=encoder_key_mask, kv=kv, skip=True, bank=bank, slot=slot)
+        h = self._ln(a, r, self.encoder_attn_layer_norm)
+        a, r = ops.mlp2_skip(h, self.fc1.weight, self.s_fc1, self.s_fc2)
+        return self._ln(a, r, self.final_layer_norm)
 
 
 class BartEncoder(nn.Module):
@@ -358,6 +371,18 @@ class BartDecoder(nn.Module):
         self.layers = nn.ModuleList([BartDecoderLayer(config) for _ in range(config.decoder_layers)])
         self.layernorm_embedding = nn.LayerNorm(d)
 
+    def arena_groups(self):
+        """all layers' cross-attention k|v parameters adjacent ([k0, v0, k1, v1, ...]): ONE GEMM X[B*S, d] . W[L*2d, d]^T projects the
+        encoder output for every layer (the reference recomputes k_proj / v_proj of the same states per layer, MFULL:478-484),
+        and its backward is one dgrad with K = L*2d and one weight gradient."""
+        ats = [l.encoder_attn for l in self.layers]
+        return [[p for a in ats for p in (a.k_proj.weight, a.v_proj.weight)], [p for a in ats for p in (a.k_proj.bias, a.v_proj.bias)]]
+
+    def bind_arena(self, a):
+        ws, bs = self.arena_groups()
+        t = a.trainable
+        self.s_kv_all = LinearSpec(a.fused(ws, "w16"), a.fused(bs, "f32"), a.fused(ws, "grad") if t else None, a.fused(bs, "grad") if t else None)
+
     def forward(self, input_ids, encoder_hidden_states, encoder_attention_mask, output_hidden_states=True):
         ln = self.layernorm_embedding
         h = ops.embed_ln(input_ids, self.embed_tokens.weight, self.embed_positions.weight, ln.weight, ln.bias, self.embed_scale,
@@ -365,9 +390,10 @@ class BartDecoder(nn.Module):
         enc_mask = encoder_attention_mask.to(torch.uint8) if encoder_attention_mask.dtype != torch.uint8 else encoder_attention_mask
         states = [h] if output_hidden_states else None
         n = len(self.layers)
+        kv_all = ops.linear(encoder_hidden_states, self.layers[0].encoder_attn.k_proj.weight, self.s_kv_all)     # [B, S, n*2d]
+        kvs, bank = ops.split_kv(kv_all, n)
         for i, layer in enumerate(self.layers):
-            enc, encoder_hidden_states = ops.fork(encoder_hidden_states) if i + 1 < n else (encoder_hidden_states, None)
-            h = layer(h, enc, enc_mask)
+            h = layer(h, None, enc_mask, kv=kvs[i], bank=bank, slot=i)
             if output_hidden_states:
                 h, keep = ops.fork(h)          # every state has two consumers (next layer / lm_head, and the caller)
                 states.append(keep)

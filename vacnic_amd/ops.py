@@ -99,10 +99,13 @@ def _wgrad_impl(dy2d, x2d, spec, M):
 
 # ------------------------------------------------------------------------------------------- Linear
 class LinearFn(Function):
-    """y = x W^T + b (+ residual).  nn.Linear on the path: q/kv/out projections, visual_map, _linear_1."""
+    """y = x W^T + b (+ residual).  nn.Linear on the path: q/kv/out projections, visual_map, _linear_1.
+    skip=True: also returns x itself as a second output (the residual branch of a post-LN block, MFULL:697,711): the
+    gradient fan-in of x — dgrad of this Linear + the gradient arriving on the skip branch — is then the `residual` input of
+    the dgrad GEMM's epilogue instead of a separate add kernel over [B*S, d]."""
 
     @staticmethod
-    def forward(ctx, x, anchor, spec, residual, ge):
+    def forward(ctx, x, anchor, spec, residual, ge, skip):
         Kd = spec.K
         x2 = _c(x).view(-1, Kd)
         M = x2.shape[0]
@@ -113,24 +116,34 @@ class LinearFn(Function):
         ctx.has_res = residual is not None
         ctx.save_for_backward(x2)
         ddp.expect(ge and any(ctx.needs_input_grad), spec.wgrad, spec.bgrad)
+        if skip:
+            return out, x.view_as(x)
         return out
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         (x2,) = ctx.saved_tensors
         spec, M = ctx.spec, ctx.M
         dy2 = _c(dy).view(M, spec.N)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, spec.K), device=dy.device, dtype=BF16)
-            K.gemm(dy2, spec.w16, M, spec.K, spec.N, out=dx, ldw=spec.ldw, w_kstrided=True)
+            K.gemm(dy2, spec.w16, M, spec.K, spec.N, out=dx, ldw=spec.ldw, w_kstrided=True,
+                   residual=_c(dskip).view(M, spec.K) if dskip is not None else None)
             dx = dx.view(dy.shape[:-1] + (spec.K,))
         _wgrad(dy2, x2, spec, M)
-        return dx, None, None, (dy if ctx.has_res else None), None
+        return dx, None, None, (dy if ctx.has_res else None), None, None
 
 
 def linear(x, anchor, spec, residual=None):
-    return LinearFn.apply(x, anchor, spec, residual, torch.is_grad_enabled())
+    return LinearFn.apply(x, anchor, spec, residual, torch.is_grad_enabled(), False)
+
+
+def linear_skip(x, anchor, spec):
+    """(linear(x), x): the skip output replaces ops.fork(x) when x's other consumer starts with this Linear."""
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return linear(x, anchor, spec), x
+    return LinearFn.apply(x, anchor, spec, None, True, True)
 
 
 # --------------------------------------------------------------------------------------------- MLP2
@@ -140,7 +153,7 @@ class Mlp2Fn(Function):
     The activation backward is fused into the dgrad GEMM epilogue (dact_src)."""
 
     @staticmethod
-    def forward(ctx, x, anchor, s1, s2, act, ge):
+    def forward(ctx, x, anchor, s1, s2, act, ge, skip=False):
         x2 = _c(x).view(-1, s1.K)
         M = x2.shape[0]
         need = ge and any(ctx.needs_input_grad)      # grad mode is always off inside Function.forward: `ge` comes from the caller
@@ -152,10 +165,12 @@ class Mlp2Fn(Function):
         ctx.s1, ctx.s2, ctx.act, ctx.M = s1, s2, act, M
         ctx.save_for_backward(x2, u, h)
         ddp.expect(need, s1.wgrad, s1.bgrad, s2.wgrad, s2.bgrad)
+        if skip:
+            return out, x.view_as(x)             # residual branch: its gradient joins in the last dgrad GEMM's epilogue
         return out
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         x2, u, h = ctx.saved_tensors
         s1, s2, act, M = ctx.s1, ctx.s2, ctx.act, ctx.M
         dy2 = _c(dy).view(M, s2.N)
@@ -167,14 +182,22 @@ class Mlp2Fn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, s1.K), device=dy.device, dtype=BF16)
-            K.gemm(du, s1.w16, M, s1.K, s1.N, out=dx, ldw=s1.ldw, w_kstrided=True)
+            K.gemm(du, s1.w16, M, s1.K, s1.N, out=dx, ldw=s1.ldw, w_kstrided=True,
+                   residual=_c(dskip).view(M, s1.K) if dskip is not None else None)
             dx = dx.view(dy.shape[:-1] + (s1.K,))
         _wgrad(du, x2, s1, M)
-        return dx, None, None, None, None, None
+        return dx, None, None, None, None, None, None
 
 
 def mlp2(x, anchor, s1, s2, act="gelu"):
-    return Mlp2Fn.apply(x, anchor, s1, s2, act, torch.is_grad_enabled())
+    return Mlp2Fn.apply(x, anchor, s1, s2, act, torch.is_grad_enabled(), False)
+
+
+def mlp2_skip(x, anchor, s1, s2, act="gelu"):
+    """(mlp2(x), x) — see linear_skip."""
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return mlp2(x, anchor, s1, s2, act), x
+    return Mlp2Fn.apply(x, anchor, s1, s2, act, True, True)
 
 
 class MlpChainFn(Function):
@@ -269,16 +292,18 @@ class SelfAttnFn(Function):
 
 
 class CrossAttnFn(Function):
-    """q: [B,Tq,d]; kv: [B,Tk,2d] = [K | V]."""
+    """q: [B,Tq,d]; kv: [B,Tk,2d] = [K | V] (any row stride: e.g. one layer's slice of the batched decoder K|V buffer).
+    bank / slot: when kv is output `slot` of SplitKvFn, dK|dV are written straight into the bank's [B,Tk,L*2d] gradient buffer."""
 
     @staticmethod
-    def forward(ctx, q, kv, key_mask, H, ge):
+    def forward(ctx, q, kv, key_mask, H, ge, bank=None, slot=0):
         B, Tq, d = q.shape
         Tk = kv.shape[1]
         out, lse = K.attn_fwd(q, kv[..., :d], kv[..., d:], B, H, Tq, Tk, key_mask=key_mask, causal=False, scale=0.125,
                               need_lse=ge and any(ctx.needs_input_grad))
         ctx.cfg = (B, H, Tq, Tk, d)
         ctx.key_mask = key_mask
+        ctx.bank, ctx.slot = bank, slot
         ctx.save_for_backward(q, kv, out, lse)
         return out
 
@@ -287,18 +312,70 @@ class CrossAttnFn(Function):
         q, kv, out, lse = ctx.saved_tensors
         B, H, Tq, Tk, d = ctx.cfg
         dq = torch.empty_like(q)
-        dkv = torch.empty_like(kv)
+        if ctx.bank is not None:
+            dkv = ctx.bank.grad_slot(ctx.slot)
+        else:
+            dkv = torch.empty((B, Tk, 2 * d), device=kv.device, dtype=BF16)
         K.attn_bwd(q, kv[..., :d], kv[..., d:], out, _c(dout), lse, dq, dkv[..., :d], dkv[..., d:], B, H, Tq, Tk,
                    key_mask=ctx.key_mask, causal=False, scale=0.125)
-        return dq, dkv, None, None, None
+        return dq, dkv, None, None, None, None, None
+
+
+class KvBank:
+    """The batched K|V projection of ONE source for L cross-attentions ([B, Tk, L*2d], layer l at columns [l*2d, (l+1)*2d)) and,
+    in backward, the gradient buffer of the same layout that the L attention backwards fill slot by slot."""
+
+    def __init__(self, kv_all, L):
+        self.kv_all, self.L = kv_all, L
+        self.w = kv_all.shape[-1] // L
+        self.dkv_all = None
+
+    def slot(self, t, l):
+        return t[..., l * self.w:(l + 1) * self.w]
+
+    def grad_slot(self, l):
+        if self.dkv_all is None:
+            self.dkv_all = torch.empty_like(self.kv_all)
+        return self.slot(self.dkv_all, l)
+
+
+class SplitKvFn(Function):
+    """kv_all [B,Tk,L*2d] -> L strided views.  Backward: each incoming gradient is (normally) already the matching slot of the
+    bank's gradient buffer, written in place by CrossAttnFn.backward, so the fan-in is free; anything else is copied in."""
+
+    @staticmethod
+    def forward(ctx, kv_all, bank):
+        ctx.bank = bank
+        return tuple(bank.slot(kv_all, l) for l in range(bank.L))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        bank = ctx.bank
+        for l, g in enumerate(grads):
+            dst = bank.grad_slot(l)
+            if g is None:
+                K.zero_strided(dst)
+            elif g.data_ptr() != dst.data_ptr() or g.stride() != dst.stride():
+                K.copy3d(_c(g), dst, g.shape[0], g.shape[1], g.shape[2])
+        out = bank.dkv_all
+        bank.dkv_all = None
+        return out, None
+
+
+def split_kv(kv_all, L):
+    """(views, bank) for L cross-attentions over one batched K|V projection."""
+    bank = KvBank(kv_all, L)
+    if not (torch.is_grad_enabled() and kv_all.requires_grad):
+        return [bank.slot(kv_all, l) for l in range(L)], None
+    return list(SplitKvFn.apply(kv_all, bank)), bank
 
 
 def self_attention(kvq, key_mask, causal, H):
     return SelfAttnFn.apply(kvq, key_mask, causal, H, torch.is_grad_enabled())
 
 
-def cross_attention(q, kv, key_mask, H):
-    return CrossAttnFn.apply(q, kv, key_mask, H, torch.is_grad_enabled())
+def cross_attention(q, kv, key_mask, H, bank=None, slot=0):
+    return CrossAttnFn.apply(q, kv, key_mask, H, torch.is_grad_enabled(), bank, slot)
 
 
 # -------------------------------------------------------------------------------------------- LN family
