@@ -171,12 +171,19 @@ def check(status):
         raise VacnicError(f"vacnic_hip status {status}: {msg}")
 
 
+CALLS = 0          # number of C-ABI calls issued so far (bench.py reports calls per step)
+
+
 def call_struct(name, **kw):
     """Call a struct-taking entry point: call_struct('vacnic_gemm_bf16', stream=s, x=ptr, ...)."""
+    global CALLS
+    CALLS += 1
     stream = kw.pop("stream")
     st = _STRUCT_FNS[name](**kw)
     check(getattr(lib, name)(C.byref(st), stream))
 
 
 def call(name, *args):
+    global CALLS
+    CALLS += 1
     check(getattr(lib, name)(*args))

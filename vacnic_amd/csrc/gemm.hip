@@ -232,7 +232,6 @@ static int gemm_one(const vacnic_gemm_args* a, int tile_hint, void* stream, int 
   // the bf16 epilogue addresses its outputs through 32-bit buffer offsets: larger outputs take the fp32-staged path
   if (((a->M - 1) * a->ldo + a->N) * 2 >= 0x7ffffff0LL) p.debug |= 16;
   if ((a->preact != nullptr) + (a->dact_src != nullptr) + (a->residual != nullptr) > 1) p.debug |= 16;   // bf16 epilogue: one extra operand
-  if (ce_mode) p.debug |= 16;
   const bool big = force == 256;
   const bool mid = force == 128;
   // A/B baselines kept for the ablations in profiles/: plain K loops and the 64-wide software-pipelined loop
@@ -240,6 +239,7 @@ static int gemm_one(const vacnic_gemm_args* a, int tile_hint, void* stream, int 
   if (force == 261) return launch_t261(p, a->x_kstrided, a->w_kstrided, zsplits, s);
   if (force == 262) return launch_t262(p, a->x_kstrided, a->w_kstrided, zsplits, s);
   if (force == 264) return launch_t264(p, a->x_kstrided, a->w_kstrided, zsplits, s);   // ping-pong, half-width tile
+  if (ce_mode) return launch_t256ce(p, a->x_kstrided, a->w_kstrided, zsplits, s);
   if (big) return launch_t256(p, a->x_kstrided, a->w_kstrided, zsplits, s);   // ping-pong loop
   if (mid) return launch_t128(p, a->x_kstrided, a->w_kstrided, zsplits, s);
   return launch_t64(p, a->x_kstrided, a->w_kstrided, zsplits, s);

@@ -22,7 +22,7 @@ struct GemmP {
   unsigned x_bytes, w_bytes;
   int tiles_m, tiles_n;
   int ce_col0;          // out_mode 3 / 4: global vocabulary index of this launch's column 0 (targets are global ids)
-  int debug;            // profiling aid (tile_hint >= 1000): bit0 skip the global stores, bit1 skip the K loop, bit2 skip the epilogue, bit3 return at once, bit4 fp32 staged epilogue, bit5 no LDS-DMA in the loop, bit6 one workgroup per tile (not persistent), bit7 no fragment reads
+  int debug;            // profiling aid (tile_hint >= 1000): bit0 skip the global stores, bit1 skip the K loop, bit2 skip the epilogue, bit3 return at once, bit4 fp32 staged epilogue, bit5 no LDS-DMA in the loop, bit7 no fragment reads
 };
 
 // f(k) of the K-strided swizzle: distinct for the 8 k-rows one tr-read half touches.
@@ -93,36 +93,6 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int rbase, int
     }
     return r;
   }
-}
-
-// ---- "half-row" staging of a K-CONTIGUOUS operand for the ping-pong loop: stage s = (K-step J = s >> 1 of 64 k, row half s & 1)
-// holds rows [half * ROWS/2, +ROWS/2) x 64 k as 128-byte LDS rows (chunk' = chunk ^ (row & 7)).  Every LDS-DMA piece then reads
-// 8 rows x 128 contiguous bytes = whole cache lines.  With 32-wide K stages a piece read 16 rows x 64 bytes: each 128-byte line
-// crossed the CU's vector L1 twice (once per K half, a stage apart), and the feed ran at 55-58 GB/s per CU against the
-// 76-78 GB/s of whole-line rows (tools/dma_probe.hip, profiles/r2_dma_probe.txt) — below what the MFMAs of a 256x256 tile eat.
-template <int ROWS, int NWAVE>
-__device__ __forceinline__ void stage_half(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, int r0, int R, int k0, int kend, int ld,
-                                           int half, int wave, int lane, bool ab_halfline = false) {
-  constexpr int PIECES = (ROWS / 2) * 128 / 1024 / NWAVE;
-  static_assert(PIECES >= 1, "tile too small for this wave count");
-#pragma unroll
-  for (int i = 0; i < PIECES; ++i) {
-    const int blk = wave * PIECES + i;
-    const int row = blk * 8 + (lane >> 3);               // row inside the half
-    const int kch = (lane & 7) ^ (row & 7);
-    int gr = r0 + half * (ROWS / 2) + row, gk = k0 + kch * 8;
-    if (ab_halfline) {       // A/B (debug bit 9, results are WRONG): the round-1 access shape, 16 rows x 64 B per piece, same bytes
-      gr = r0 + blk * 16 + (lane >> 2); gk = k0 + half * 32 + (lane & 3) * 8;
-    }
-    const int voff = (gr < R && gk < kend) ? (int)(((unsigned)gr * (unsigned)ld + (unsigned)gk) * 2u) : OOB;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + blk * 1024), 16, voff, 0, 0, 0);
-  }
-}
-// fragment of rows rloc..rloc+15 (inside the half), k-substep kk (0/1) of the stage's 64 k
-__device__ __forceinline__ bf16x8 read_half(const char* lds_tile, int rloc, int kk, int lane) {
-  const int row = rloc + (lane & 15);
-  const int chunk = kk * 4 + (lane >> 4);
-  return *(const bf16x8*)(lds_tile + row * 128 + ((chunk ^ (row & 7)) << 4));
 }
 
 // Epilogue on 8 consecutive outputs of one row (read back from the LDS-staged C tile): bias, saved
@@ -252,30 +222,54 @@ __device__ __forceinline__ void epilogue8(const GemmP& p, float v[8], int m, int
 
 template <int V> struct IC { static constexpr int value = V; };
 
-#define VAC_OPAQUE_S(x) asm volatile("" : "+s"(x))
-
-template <int N>
-__device__ __forceinline__ void wait_vm_lgkm() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
-
-// Workgroup barrier that orders LDS traffic only: this wave's LDS operations are retired, global stores and LDS-DMA stay in
-// flight (a __syncthreads() here would also drain the store burst of the epilogue it separates from the next tile's loads).
+// Workgroup barrier that orders LDS traffic only (this wave's LDS operations retired; global stores stay in flight)
 __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 }
 
-template <int BM, int BN, int WM, int WN, int BKT, int NSTAGE, bool PIPE, bool XKS, bool WKS>
+
+
+template <int N>
+__device__ __forceinline__ void wait_vm_lgkm() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
+
+// CE: compile the fused LM-head cross-entropy epilogues (out_mode 3 / 4) — their own instantiation (gemm_t256ce.hip): inside the
+// general kernels their code raised the register allocation of EVERY epilogue path (128x128 tiles: 181 -> 256 VGPRs + scratch).
+template <int BM, int BN, int WM, int WN, int BKT, int NSTAGE, bool PIPE, bool XKS, bool WKS, bool CE = false>
 __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
   constexpr int NWAVE = WM * WN, NTHR = 64 * NWAVE;
   constexpr int TM = BM / WM, TN = BN / WN;             // per-wave output sub-tile
   constexpr int FA = TM / 16, FB = TN / 16;             // MFMA tiles per wave along m / n
   constexpr int XT = BM * BKT * 2, WT = BN * BKT * 2, STAGE = XT + WT;
-  constexpr bool PINGPONG = PIPE && BKT == 32 && NSTAGE == 4;
-  constexpr int XSN = FA / WN;                           // row-sum accumulators per wave (xsum)
-  static_assert(FA % WN == 0 && FA / WN <= 4, "xsum: row blocks split over the waves of a row group, <= 4 each");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (p.debug & 8) return;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % WM, wn = wave / WM;
+
+  // XCD-aware work order.  Workgroup L of the 1-D grid runs on XCD L % 8, each with its own 4 MiB L2.
+  //  * split-K launches (weight gradients): split z = L % nsplit, so one XCD (or nsplit/8 .. 8/nsplit of them) owns a whole
+  //    K-slice and every row of dY / X in it is fetched once — all tiles of a slice run concurrently on that XCD
+  //    (+2 % on the wgrad GEMMs; with the splits in blockIdx.z every XCD touched every K-slice).
+  //  * otherwise each XCD gets a contiguous run of tiles (bijective for any tile count), n fastest so neighbours reuse the
+  //    same X panel in their L2.  (Walking 4-column strips inside a run — an 8 x 4 block of tiles in flight instead of
+  //    2 x 16 — measured no gain: the 256 MiB memory-side cache already absorbs the W re-reads.)
+  const int nt = p.tiles_m * p.tiles_n;
+  int bid = blockIdx.x, zsplit = 0;
+  if (p.split_k > 1) {
+    zsplit = bid % p.split_k;
+    bid = bid / p.split_k;
+  } else {
+    const int q = nt >> 3, r = nt & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tm = bid / p.tiles_n, tn = bid - tm * p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int kbeg = zsplit * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+  const int ntile = (p.debug & 2) ? 0 : (kend - kbeg + BKT - 1) / BKT;
 
   __amdgpu_buffer_rsrc_t xs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
@@ -284,100 +278,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
   const int RX = XKS ? ((p.M + 7) & ~7) : p.M;
   const int RW = WKS ? ((p.N + 7) & ~7) : p.N;
 
-  // ---- work loop.  The ping-pong configurations are launched PERSISTENT (one workgroup per CU, grid = #CUs): workgroup L
-  // takes work items L, L + grid, ...; the global stores of tile i are still draining (HBM-write bound: a round of 256
-  // tiles leaves 32 MiB at once) while tile i+1 loads and multiplies.  Every other configuration is launched with one
-  // workgroup per work item and runs this loop once.
-  // XCD-aware work order.  Workgroup L of the 1-D grid runs on XCD L % 8, each with its own 4 MiB L2 (grid % 8 == 0 when
-  // persistent, so a workgroup stays on "its" XCD run for all its items).
-  //  * split-K launches (weight gradients): split z = L % nsplit, so one XCD (or nsplit/8 .. 8/nsplit of them) owns a whole
-  //    K-slice and every row of dY / X in it is fetched once — all tiles of a slice run concurrently on that XCD
-  //    (+2 % on the wgrad GEMMs; with the splits in blockIdx.z every XCD touched every K-slice).
-  //  * otherwise each XCD gets a contiguous run of tiles (bijective for any tile count), n fastest so neighbours reuse the
-  //    same X panel in their L2.  (Walking 4-column strips inside a run — an 8 x 4 block of tiles in flight instead of
-  //    2 x 16 — measured no gain: the 256 MiB memory-side cache already absorbs the W re-reads.)
-  const int nt = p.tiles_m * p.tiles_n;
-  const int total = nt * p.split_k;
-  struct Work { int m0, n0, kbeg, kend, tn, zsplit; };
-  auto coords = [&](int v) {
-    Work k;
-    int bid = v;
-    k.zsplit = 0;
-    if (p.split_k > 1) {
-      k.zsplit = bid % p.split_k;
-      bid = bid / p.split_k;
-    } else {
-      const int q = nt >> 3, r = nt & 7, xcd = bid & 7;
-      bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int tm = bid / p.tiles_n;
-    k.tn = bid - tm * p.tiles_n;
-    k.m0 = tm * BM; k.n0 = k.tn * BN;
-    k.kbeg = k.zsplit * p.k_per_split;
-    k.kend = min(p.K, k.kbeg + p.k_per_split);
-    return k;
-  };
-  // LDS: NSTAGE-deep ring, stage s at smem + s*STAGE = {X tile, W tile}.  Tiles t+1 .. t+NSTAGE-1 are in flight
-  // while tile t is multiplied; one barrier per K-tile.  Loads are issued unconditionally (a tile past kend is
-  // all out-of-range -> zero fill, never read) so the counted vmcnt below is a compile-time constant.
-  constexpr int LOADS = (BM + BN) * BKT * 2 / 1024 / NWAVE;   // LDS-DMA instructions per wave per K-tile
-  static_assert(LOADS * (NSTAGE - 2) <= 63, "vmcnt immediate");
-  constexpr bool PIPED = PIPE && BKT == 64 && NSTAGE == 2;
-  constexpr int PRO = PIPED ? 2 : NSTAGE - 1;            // tiles staged before the loop
-  // ping-pong ring: 5 slots (160 KiB: all of a CU's LDS).  Stage s of a K-contiguous operand = row half (s & 1) of the 64-wide
-  // K-step s >> 1 (stage_half); stage s of a K-strided operand = its 32 k-rows [32 s, 32 s + 32) of all rows, as before.
-  constexpr int NSLOT = 5;
-  auto stage_pp = [&](const Work& k, int s, char* slot, int wave_, int lane_) {
-    if constexpr (XKS) stage_tile<true, BM, BKT, NWAVE>(xs, slot, k.m0, RX, k.kbeg + s * BKT, k.kend, p.ldx, wave_, lane_);
-    else stage_half<BM, NWAVE>(xs, slot, k.m0, RX, k.kbeg + (s >> 1) * 64, k.kend, p.ldx, s & 1, wave_, lane_, (p.debug & 512) != 0);
-    if constexpr (WKS) stage_tile<true, BN, BKT, NWAVE>(ws, slot + XT, k.n0, RW, k.kbeg + s * BKT, k.kend, p.ldw, wave_, lane_);
-    else stage_half<BN, NWAVE>(ws, slot + XT, k.n0, RW, k.kbeg + (s >> 1) * 64, k.kend, p.ldw, s & 1, wave_, lane_, (p.debug & 512) != 0);
-  };
-  auto prologue = [&](const Work& k, int wave_, int lane_) {
-#pragma unroll
-    for (int s = 0; s < PRO; ++s) {
-      if constexpr (PINGPONG) {
-        stage_pp(k, s, smem + s * STAGE, wave_, lane_);
-      } else {
-        stage_tile<XKS, BM, BKT, NWAVE>(xs, smem + s * STAGE, k.m0, RX, k.kbeg + s * BKT, k.kend, p.ldx, wave_, lane_);
-        stage_tile<WKS, BN, BKT, NWAVE>(ws, smem + s * STAGE + XT, k.n0, RW, k.kbeg + s * BKT, k.kend, p.ldw, wave_, lane_);
-      }
-    }
-  };
-  // bf16 epilogue geometry (256-row tiles): 16-byte chunks per staged row, rows per sweep of the workgroup, sweeps (= 16-byte
-  // global stores per thread) per tile
-  constexpr int ROWB = BN * 2, NCH = ROWB / 16, RSTEP = NTHR / NCH, NIT = BM / RSTEP;
-  static_assert(!PINGPONG || 2 * LOADS + 2 * NIT <= 63, "vmcnt immediate (stores in flight behind the next tile's loads)");
-  int vb = blockIdx.x;
-  if (vb >= total) return;
-  Work wk = coords(vb);
-  prologue(wk, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), threadIdx.x & 63);
-  // `pend`: global stores of the previous tile's epilogue that this wave issued AFTER this tile's prologue loads (0, NIT or
-  // 2*NIT; exactly that many wave-instructions, buffer stores never skip).  vmcnt counts loads and stores together in issue
-  // order, so until those stores have retired the waits for the first stages allow `pend` more operations in flight —
-  // the store burst of tile i (HBM-write bound) drains behind the first K-steps of tile i+1 instead of in front of them.
-  int pend = 0;
-  for (;;) {
-  // per-lane indices are re-derived from an opaque copy of the thread index for every work item (and once more for the
-  // epilogue): otherwise every per-lane address of the K loop AND of the epilogue is hoisted out of the work loop and
-  // kept live across both, which does not fit the 256-VGPR budget of the 8-wave tiles
-  int tid = threadIdx.x;
-  asm volatile("" : "+v"(tid));
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave % WM, wn = wave / WM;
-  const int lm = lane & 15;
-  const int zsplit = wk.zsplit, tn = wk.tn;
-  const int m0 = wk.m0, n0 = wk.n0;
-  const int kbeg = wk.kbeg, kend = wk.kend;
-  const int ntile = (p.debug & 2) ? 0 : (kend - kbeg + BKT - 1) / BKT;
-
   f32x4 acc[FB][FA];
 #pragma unroll
   for (int b = 0; b < FB; ++b)
 #pragma unroll
     for (int a = 0; a < FA; ++a) acc[b][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  constexpr int XSN = FA / WN;                           // row-sum accumulators per wave (xsum)
+  static_assert(FA % WN == 0 && FA / WN <= 4, "xsum: row blocks split over the waves of a row group, <= 4 each");
   // xsum[m] += sum_k X(m,k) (the bias gradient of a weight-gradient GEMM: X = dY; compiled into the both-K-strided layout
   // only).  One extra MFMA per 16 rows re-uses the X fragments that are in registers anyway: the A operand is a row
   // selector (row i all ones, the other rows zero), so the XSN row blocks a wave is responsible for land in rows 0..XSN-1
@@ -393,7 +301,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
     _Pragma("unroll") for (int w_ = 0; w_ < WN; ++w_)                                       \
       if (wn == w_) {                                                                       \
         _Pragma("unroll") for (int i = 0; i < XSN; ++i) {                                   \
-          const short o_ = lm == i ? (short)0x3F80 : (short)0;                              \
+          const short o_ = (lane & 15) == i ? (short)0x3F80 : (short)0;                              \
           const bf16x8 sel_ = {o_, o_, o_, o_, o_, o_, o_, o_};                             \
           accs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sel_, XF[w_ * XSN + i], accs, 0, 0, 0); \
         }                                                                                   \
@@ -405,16 +313,23 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
     xs_next += p.tiles_n;                                                                   \
   }
 
-  // tile 0 landed (this wave's pieces; the stores counted in `pend` are younger than all prologue loads)
-  // (ping-pong: the first K-step reads stages 0 AND 1, so only stage 2 — and the `pend` stores — may still fly)
-  if (PINGPONG && pend == NIT) wait_vm_lgkm<LOADS + NIT>();
-  else if (PINGPONG && pend != 0) wait_vm_lgkm<LOADS + 2 * NIT>();
-  else if (PINGPONG) wait_vm_lgkm<LOADS>();
-  else wait_vm_lgkm<LOADS * (PRO - 1)>();
+  // LDS: NSTAGE-deep ring, stage s at smem + s*STAGE = {X tile, W tile}.  Tiles t+1 .. t+NSTAGE-1 are in flight
+  // while tile t is multiplied; one barrier per K-tile.  Loads are issued unconditionally (a tile past kend is
+  // all out-of-range -> zero fill, never read) so the counted vmcnt below is a compile-time constant.
+  constexpr int LOADS = (BM + BN) * BKT * 2 / 1024 / NWAVE;   // LDS-DMA instructions per wave per K-tile
+  static_assert(LOADS * (NSTAGE - 2) <= 63, "vmcnt immediate");
+  constexpr bool PIPED = PIPE && BKT == 64 && NSTAGE == 2;
+  constexpr int PRO = PIPED ? 2 : NSTAGE - 1;            // tiles staged before the loop
+#pragma unroll
+  for (int s = 0; s < PRO; ++s) {
+    stage_tile<XKS, BM, BKT, NWAVE>(xs, smem + s * STAGE, m0, RX, kbeg + s * BKT, kend, p.ldx, wave, lane);
+    stage_tile<WKS, BN, BKT, NWAVE>(ws, smem + s * STAGE + XT, n0, RW, kbeg + s * BKT, kend, p.ldw, wave, lane);
+  }
+  wait_vm_lgkm<LOADS * (PRO - 1)>();                     // tile 0 landed
   __builtin_amdgcn_s_barrier();
   int cur = 0, nxt = NSTAGE - 1;
-  if constexpr (PINGPONG) {
-    // Ping-pong K loop (8 waves, two per SIMD; 32-wide K substeps over a 5-slot ring of 32-KiB stages).  The waves of a workgroup form two
+  if constexpr (PIPE && BKT == 32 && NSTAGE == 4) {
+    // Ping-pong K loop (8 waves, two per SIMD; 32-wide K stages in a 4-slot ring).  The waves of a workgroup form two
     // groups, A = waves 0..3 and B = waves 4..7 (SIMD partners), that run the same sequence one interval apart:
     //     A:  MEM(0) | COMP(0) | MEM(1) | COMP(1) | ...
     //     B:    -    | MEM(0)  | COMP(0)| MEM(1)  | ...          ('|' = workgroup barrier)
@@ -423,6 +338,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
     // LDS / vector-memory issue ports, so neither the fragment reads nor the ~60-100-cycle issue cost of an LDS-DMA piece
     // ever stalls the MFMA stream (measured before: MFMA-only loop 1.0 us per 64-K, +0.27 us for the LDS reads, +0.34 us
     // for the DMA issue when both partners do the same thing at the same time).
+    // Ring safety: stage j is read by A in interval 2j and by B in interval 2j+1; MEM(j+1) (intervals 2j+2 / 2j+3) refills
+    // its slot with stage j+4.  A wave leaves MEM(h) only when its own pieces of stage h+1 have landed (vmcnt(8): stages
+    // h+2, h+3 may fly), and a barrier separates that from every later reader.
     static_assert(NWAVE == 8 && LOADS >= 2, "ping-pong loop is written for 8 waves (two per SIMD)");
     // (Issuing part of the DMA pieces in the middle of COMP(h) instead, or staggering the partners' issue points in a 64-wide
     // pipelined loop, measured the same within noise: profiles/r1_gemm_overhead.txt.)
@@ -430,50 +348,22 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
     const int nst = ntile;
     bf16x8 xf[FA], wf[FB];
     if (grp_b) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
-    // Ring bookkeeping (5 slots, stage s in slot s % 5).  Substep h = K-step J = h >> 1, half kk = h & 1.  MEM(h) reads the
-    // K-contiguous operands from the slots of stages 2J (row half 0) and 2J + 1 (row half 1) at k-offset 32 kk — a wave's X
-    // rows all lie in half wm, its W rows in half wn >> 1 — and the K-strided operands from the slot of stage h; it issues
-    // this wave's pieces of stage h + 3, whose slot (stage h - 2) is dead: the stages of K-step J are read in intervals
-    // 4J .. 4J + 3 (group A: MEM(2J), MEM(2J+1); group B one interval later) and h - 2 belongs to K-step J - 1 for both parities.
-    // Landing: MEM(h + 1) reads stages <= h + 2 when h + 1 is even (a new K-step: both of its stages) and <= h + 1 when odd,
-    // so a wave leaves MEM(h) with at most stage h + 3 (h odd) or h + 2, h + 3 (h even) of its own pieces in flight.
-    int s0 = 0;                                            // slot of stage h
+    int rd = 0, wr = 3;
     for (int h = 0; h < nst; ++h) {
-      const int kk = h & 1;
-      const int se = kk ? (s0 == 0 ? NSLOT - 1 : s0 - 1) : s0;                 // slot of stage 2J
-      const int so = kk ? s0 : (s0 + 1 == NSLOT ? 0 : s0 + 1);                 // slot of stage 2J + 1
-      const int sw = s0 + 3 >= NSLOT ? s0 + 3 - NSLOT : s0 + 3;                // slot of stage h + 3
+      const char* xr = smem + rd * STAGE;
+      char* xw = smem + wr * STAGE;
       if (!(p.debug & 128) || h == 0) {
-        if constexpr (XKS) {
 #pragma unroll
-          for (int a = 0; a < FA; ++a) xf[a] = read_frag<true, BM, BKT>(smem + s0 * STAGE, wm * TM + a * 16, 0, lane);
-        } else {
-          static_assert(TM <= BM / 2 && (BM / 2) % TM == 0, "a wave's rows must lie in one row half");
-          const char* xb = smem + ((wm * TM) / (BM / 2) ? so : se) * STAGE;
+        for (int a = 0; a < FA; ++a) xf[a] = read_frag<XKS, BM, BKT>(xr, wm * TM + a * 16, 0, lane);
 #pragma unroll
-          for (int a = 0; a < FA; ++a) xf[a] = read_half(xb, (wm * TM) % (BM / 2) + a * 16, kk, lane);
-        }
-        if constexpr (WKS) {
-#pragma unroll
-          for (int b = 0; b < FB; ++b) wf[b] = read_frag<true, BN, BKT>(smem + s0 * STAGE + XT, wn * TN + b * 16, 0, lane);
-        } else {
-          static_assert(TN <= BN / 2 && (BN / 2) % TN == 0, "a wave's columns must lie in one row half of W");
-          const char* wb = smem + ((wn * TN) / (BN / 2) ? so : se) * STAGE + XT;
-#pragma unroll
-          for (int b = 0; b < FB; ++b) wf[b] = read_half(wb, (wn * TN) % (BN / 2) + b * 16, kk, lane);
-        }
+        for (int b = 0; b < FB; ++b) wf[b] = read_frag<WKS, BN, BKT>(xr + XT, wn * TN + b * 16, 0, lane);
       }
-      if (!(p.debug & 32)) stage_pp(wk, h + 3, smem + sw * STAGE, wave, lane);
-      // counted wait (see "Landing"); during MEM(0) the previous tile's stores, issued between this tile's prologue loads and
-      // stage 3, may still fly — by the end of MEM(1) they are older than a stage that must have landed
-      if (kk) {
-        wait_vm_lgkm<LOADS>();
-      } else if (h == 0 && pend != 0) {
-        if (pend == NIT) wait_vm_lgkm<2 * LOADS + NIT>();
-        else wait_vm_lgkm<2 * LOADS + 2 * NIT>();
-      } else {
-        wait_vm_lgkm<2 * LOADS>();
+      if (!(p.debug & 32)) {
+        stage_tile<XKS, BM, BKT, NWAVE>(xs, xw, m0, RX, kbeg + (h + 3) * BKT, kend, p.ldx, wave, lane);
+        stage_tile<WKS, BN, BKT, NWAVE>(ws, xw + XT, n0, RW, kbeg + (h + 3) * BKT, kend, p.ldw, wave, lane);
       }
+      // stage h+1 must have landed (this wave's pieces); newer ones may fly
+      wait_vm_lgkm<2 * LOADS>();
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
@@ -488,7 +378,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      s0 = s0 + 1 == NSLOT ? 0 : s0 + 1;
+      rd = (rd + 1) & 3;
+      wr = (wr + 1) & 3;
     }
     if (!grp_b) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
   } else if constexpr (PIPED) {
@@ -549,6 +440,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
       stage_tile<XKS, BM, BKT, NWAVE>(xs, xnext, m0, RX, kbeg + (t + NSTAGE - 1) * BKT, kend, p.ldx, wave, lane);
       stage_tile<WKS, BN, BKT, NWAVE>(ws, xnext + XT, n0, RW, kbeg + (t + NSTAGE - 1) * BKT, kend, p.ldw, wave, lane);
     }
+    if (!(p.debug & 64))
 #pragma unroll
     for (int kk = 0; kk < BKT / 32; ++kk) {
       if (!(p.debug & 128) || t == 0) {
@@ -572,11 +464,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
     nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
   }
   }
-#undef VAC_XSUM
-#undef VAC_XSUM_MFMA
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the (zero-fill) tail loads before LDS is reused
   __builtin_amdgcn_s_barrier();
-
+#undef VAC_XSUM
+#undef VAC_XSUM_MFMA
   if (XS && xs_on && lane < 16) {
     // C^T layout: lanes 0..15 hold result rows 0..3 (element j = row), column m = lane
 #pragma unroll
@@ -586,78 +477,65 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
     }
   }
 
-  // The epilogue reads its parameters through opaque copies: inside the persistent work loop everything derived from the
-  // kernel arguments and the thread index is loop-invariant, and hoisting it all (dozens of precomputed branch masks and
-  // per-lane addresses) ahead of the loop spilled the K loop's fragment addresses to scratch.
-  GemmP q = p;
-  VAC_OPAQUE_S(q.bias); VAC_OPAQUE_S(q.out); VAC_OPAQUE_S(q.preact); VAC_OPAQUE_S(q.dact_src); VAC_OPAQUE_S(q.residual);
-  VAC_OPAQUE_S(q.M); VAC_OPAQUE_S(q.N); VAC_OPAQUE_S(q.ldo); VAC_OPAQUE_S(q.act); VAC_OPAQUE_S(q.out_mode);
-  VAC_OPAQUE_S(q.split_k); VAC_OPAQUE_S(q.alpha); VAC_OPAQUE_S(q.debug);
-  int te = threadIdx.x;
-  asm volatile("" : "+v"(te));
-  const int wve = __builtin_amdgcn_readfirstlane(te >> 6);
-  const int le = te & 63, lme = le & 15, ln4e = (le >> 4) * 4;
-  const int wme = wve % WM, wne = wve / WM;
-  const int vnext = vb + (int)gridDim.x;                // persistent launch: the next work item of this workgroup
-  const bool more = vnext < total;
-  Work wnx = wk;
-  if (more) wnx = coords(vnext);
-  int pend_next = 0;
-  bool done = false, staged = false;                    // staged: the next tile's prologue loads have been issued
-  if (q.debug & 4) { if (acc[0][0][0] == 12345.678f) ((float*)q.out)[0] = 0.f; done = true; }
-  // ---- direct epilogue for the common plain case (bf16 out, bias + activation only): each le owns 4 consecutive n of
+  if (p.debug & 4) { if (acc[0][0][0] == 12345.678f) ((float*)p.out)[0] = 0.f; return; }
+  // ---- direct epilogue for the common plain case (bf16 out, bias + activation only): each lane owns 4 consecutive n of
   // one m per accumulator tile -> bias as one 16-byte load, pack with v_cvt_pk_bf16_f32, one 8-byte store.  No LDS
   // round trip, no barriers; the 32-byte row pieces of the four n-groups are merged by the L2.
-  if (!done && BM <= 128 && q.out_mode == 0 && !q.preact && !q.dact_src && !q.residual && (q.ldo & 3) == 0 && !(q.debug & 16)) {
-    const bool add_bias_ = q.bias != nullptr;
+  if (BM <= 128 && p.out_mode == 0 && !p.preact && !p.dact_src && !p.residual && (p.ldo & 3) == 0 && !(p.debug & 16)) {
+    const int lm_ = lane & 15, ln4_ = (lane >> 4) * 4;
+    const bool add_bias_ = p.bias != nullptr;
 #pragma unroll
     for (int a = 0; a < FA; ++a) {
-      const int m = m0 + wme * TM + a * 16 + lme;
-      if (m >= q.M) continue;
-      bf16_t* orow = (bf16_t*)q.out + (size_t)m * q.ldo;
+      const int m = m0 + wm * TM + a * 16 + lm_;
+      if (m >= p.M) continue;
+      bf16_t* orow = (bf16_t*)p.out + (size_t)m * p.ldo;
 #pragma unroll
       for (int b = 0; b < FB; ++b) {
-        const int n = n0 + wne * TN + b * 16 + ln4e;
-        if (n + 4 <= q.N) {
+        const int n = n0 + wn * TN + b * 16 + ln4_;
+        if (n + 4 <= p.N) {
           f32x4 v = acc[b][a];
-          if (q.alpha != 1.0f) v *= q.alpha;
-          if (add_bias_) v += *(const f32x4*)(q.bias + n);
-          if (q.act != VACNIC_ACT_NONE) {
+          if (p.alpha != 1.0f) v *= p.alpha;
+          if (add_bias_) v += *(const f32x4*)(p.bias + n);
+          if (p.act != VACNIC_ACT_NONE) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = act_fwd(q.act, v[j]);
+            for (int j = 0; j < 4; ++j) v[j] = act_fwd(p.act, v[j]);
           }
           *(u32x2*)(orow + n) = (u32x2){pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-        } else if (n < q.N) {
-          for (int j = 0; j < 4 && n + j < q.N; ++j) {
-            float v = acc[b][a][j] * q.alpha + (add_bias_ ? q.bias[n + j] : 0.f);
-            orow[n + j] = f2bf(act_fwd(q.act, v));
+        } else if (n < p.N) {
+          for (int j = 0; j < 4 && n + j < p.N; ++j) {
+            float v = acc[b][a][j] * p.alpha + (add_bias_ ? p.bias[n + j] : 0.f);
+            orow[n + j] = f2bf(act_fwd(p.act, v));
           }
         }
       }
     }
-    done = true;
+    return;
   }
+  // bf16 epilogue geometry (256-row tiles): 16-byte chunks per staged row, rows per sweep of the workgroup, sweeps (= 16-byte
+  // global stores per thread) per tile
+  constexpr int ROWB = BN * 2, NCH = ROWB / 16, RSTEP = NTHR / NCH, NIT = BM / RSTEP;
+  const int lm = lane & 15, ln4 = (lane >> 4) * 4;
   // ---- bf16 epilogue of the 256-row tiles (bf16 output, 16-byte output rows): bias (+ activation when nothing else
   // needs the pre-activation) on the fp32 accumulators in registers, round ONCE to bf16 and transpose the whole C tile
   // through LDS in a single pass (BM x BN x 2 B <= 128 KiB, XOR-swizzled 16-byte chunks: conflict-free 8-byte writes
   // from the C^T fragments, conflict-free 16-byte row reads), so that every global access is a 16-byte row-contiguous
-  // one.  One barrier pair per tile instead of four fp32 passes (2 us instead of 7.7 us per 256x256 tile).  Saved
+  // one.  One barrier per tile instead of four fp32 passes.  Saved
   // pre-activation, fused activation-backward and residual are applied on the bf16 value after the transposition — the
   // arithmetic of a bf16 autocast Linear followed by a bf16 elementwise op.
   if constexpr (BM == 256 && BN >= 128) {
-    if (!done && q.out_mode == 0 && (q.ldo & 7) == 0 && (q.N & 7) == 0 && !(q.debug & 16)) {
-      static_assert(BM * ROWB <= (PINGPONG ? 5 : NSTAGE) * STAGE, "bf16 C tile must fit in the operand ring");
-      const bool act_in_regs = q.act != VACNIC_ACT_NONE && !q.preact && !q.dact_src;
+    if (p.out_mode == 0 && (p.ldo & 7) == 0 && (p.N & 7) == 0 && !(p.debug & 16)) {
+      static_assert(BM * ROWB <= NSTAGE * STAGE, "bf16 C tile must fit in the operand ring");
+      const bool act_in_regs = p.act != VACNIC_ACT_NONE && !p.preact && !p.dact_src;
       f32x4 bia[FB];
 #pragma unroll
       for (int b = 0; b < FB; ++b) {
-        const int n = n0 + wne * TN + b * 16 + ln4e;
+        const int n = n0 + wn * TN + b * 16 + ln4;
         bia[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (q.bias) {
-          if (n + 4 <= q.N) bia[b] = *(const f32x4*)(q.bias + n);
+        if (p.bias) {
+          if (n + 4 <= p.N) bia[b] = *(const f32x4*)(p.bias + n);
           else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (n + j < q.N) bia[b][j] = q.bias[n + j];
+            for (int j = 0; j < 4; ++j) if (n + j < p.N) bia[b][j] = p.bias[n + j];
           }
         }
       }
@@ -665,57 +543,51 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
         constexpr int ACT = decltype(act_c)::value;
 #pragma unroll
         for (int a = 0; a < FA; ++a) {
-          const int row = wme * TM + a * 16 + lme;
+          const int row = wm * TM + a * 16 + lm;
           char* rp = smem + row * ROWB;
 #pragma unroll
           for (int b = 0; b < FB; ++b) {
             f32x4 v = acc[b][a];
-            if (q.alpha != 1.0f) v *= q.alpha;
+            if (p.alpha != 1.0f) v *= p.alpha;
             v += bia[b];
             if (ACT != VACNIC_ACT_NONE) {
 #pragma unroll
               for (int j = 0; j < 4; ++j) v[j] = act_fwd(ACT, v[j]);
             }
-            const int nl = wne * TN + b * 16 + ln4e;
+            const int nl = wn * TN + b * 16 + ln4;
             *(u32x2*)(rp + ((((nl >> 3) ^ (row & 15)) << 4) | (((nl >> 2) & 1) << 3))) = (u32x2){pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
           }
         }
       };
-      const int act_regs = act_in_regs ? q.act : VACNIC_ACT_NONE;
+      const int act_regs = act_in_regs ? p.act : VACNIC_ACT_NONE;
       if (act_regs == VACNIC_ACT_GELU) deposit(IC<VACNIC_ACT_GELU>{});
       else if (act_regs == VACNIC_ACT_TANH) deposit(IC<VACNIC_ACT_TANH>{});
       else if (act_regs == VACNIC_ACT_QUICKGELU) deposit(IC<VACNIC_ACT_QUICKGELU>{});
       else deposit(IC<VACNIC_ACT_NONE>{});
       lds_barrier();
       static_assert(NTHR % NCH == 0 && BM % RSTEP == 0 && NIT % 8 == 0, "epilogue sweep mapping");
-      const int c = te % NCH, rb = te / NCH;
+      const int c = tid % NCH, rb = tid / NCH;
       u32x4 cv[NIT];
 #pragma unroll
       for (int k = 0; k < NIT; ++k) {
         const int row = rb + k * RSTEP;
         cv[k] = *(const u32x4*)(smem + row * ROWB + ((c ^ (row & 15)) << 4));
       }
-      if (more) {
-        // the C tile is in registers: the next tile's loads go out BEFORE this tile's stores (see `pend`)
-        lds_barrier();
-        prologue(wnx, wve, le);
-        staged = true;
-      }
       // Global traffic of the epilogue through buffer instructions: rows >= M (and, with debug bit 0, everything) fall
       // outside the descriptor's range — loads return 0, stores are dropped — so there is no branch around any access
       // (a branch per load makes hipcc wait for each load separately) and every wave issues exactly NIT stores per output.
-      const unsigned span = (unsigned)((((size_t)q.M - 1) * q.ldo + q.N) * 2);
+      const unsigned span = (unsigned)((((size_t)p.M - 1) * p.ldo + p.N) * 2);
       const int n = n0 + c * 8;
-      const unsigned rstride = (unsigned)(RSTEP * q.ldo * 2);
-      unsigned voff = (n + 8 <= q.N && !(q.debug & 1)) ? (unsigned)(((size_t)(m0 + rb) * q.ldo + n) * 2) : (unsigned)OOB;
-      const unsigned vstep = (n + 8 <= q.N && !(q.debug & 1)) ? rstride : 0u;
-      __amdgpu_buffer_rsrc_t so = __builtin_amdgcn_make_buffer_rsrc(q.out, 0, span, 0x00020000);
-      const bool plain = !q.preact && !q.dact_src && !q.residual;
+      const unsigned rstride = (unsigned)(RSTEP * p.ldo * 2);
+      unsigned voff = (n + 8 <= p.N && !(p.debug & 1)) ? (unsigned)(((size_t)(m0 + rb) * p.ldo + n) * 2) : (unsigned)OOB;
+      const unsigned vstep = (n + 8 <= p.N && !(p.debug & 1)) ? rstride : 0u;
+      __amdgpu_buffer_rsrc_t so = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, span, 0x00020000);
+      const bool plain = !p.preact && !p.dact_src && !p.residual;
       // exactly one of residual / preact / dact_src may ride on this path (the host sends combinations to the fp32 path);
       // each gets its own straight-line instance: MODE 1 residual, 2 saved pre-activation (+ activation), 3 activation backward
       auto tail = [&](auto mode_c, auto act_c) {
         constexpr int MODE = decltype(mode_c)::value, ACT = decltype(act_c)::value;
-        const void* eptr = MODE == 1 ? (const void*)q.residual : MODE == 2 ? (const void*)q.preact : (const void*)q.dact_src;
+        const void* eptr = MODE == 1 ? (const void*)p.residual : MODE == 2 ? (const void*)p.preact : (const void*)p.dact_src;
         __amdgpu_buffer_rsrc_t se = __builtin_amdgcn_make_buffer_rsrc((void*)eptr, 0, span, 0x00020000);
 #pragma unroll
         for (int k0 = 0; k0 < NIT; k0 += 8) {
@@ -746,69 +618,70 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
       if (plain) {
 #pragma unroll
         for (int k = 0; k < NIT; ++k) __builtin_amdgcn_raw_buffer_store_b128(cv[k], so, voff + k * vstep, 0, 0);
-        pend_next = NIT;
-      } else if (q.residual) {
+      } else if (p.residual) {
         tail(IC<1>{}, IC<VACNIC_ACT_NONE>{});
-        pend_next = NIT;
-      } else if (q.preact) {
-        if (q.act == VACNIC_ACT_GELU) tail(IC<2>{}, IC<VACNIC_ACT_GELU>{});
-        else if (q.act == VACNIC_ACT_TANH) tail(IC<2>{}, IC<VACNIC_ACT_TANH>{});
-        else if (q.act == VACNIC_ACT_QUICKGELU) tail(IC<2>{}, IC<VACNIC_ACT_QUICKGELU>{});
+      } else if (p.preact) {
+        if (p.act == VACNIC_ACT_GELU) tail(IC<2>{}, IC<VACNIC_ACT_GELU>{});
+        else if (p.act == VACNIC_ACT_TANH) tail(IC<2>{}, IC<VACNIC_ACT_TANH>{});
+        else if (p.act == VACNIC_ACT_QUICKGELU) tail(IC<2>{}, IC<VACNIC_ACT_QUICKGELU>{});
         else tail(IC<2>{}, IC<VACNIC_ACT_NONE>{});
-        pend_next = 2 * NIT;
       } else {
-        if (q.act == VACNIC_ACT_GELU) tail(IC<3>{}, IC<VACNIC_ACT_GELU>{});
-        else if (q.act == VACNIC_ACT_TANH) tail(IC<3>{}, IC<VACNIC_ACT_TANH>{});
-        else if (q.act == VACNIC_ACT_QUICKGELU) tail(IC<3>{}, IC<VACNIC_ACT_QUICKGELU>{});
+        if (p.act == VACNIC_ACT_GELU) tail(IC<3>{}, IC<VACNIC_ACT_GELU>{});
+        else if (p.act == VACNIC_ACT_TANH) tail(IC<3>{}, IC<VACNIC_ACT_TANH>{});
+        else if (p.act == VACNIC_ACT_QUICKGELU) tail(IC<3>{}, IC<VACNIC_ACT_QUICKGELU>{});
         else tail(IC<3>{}, IC<VACNIC_ACT_NONE>{});
-        pend_next = NIT;
       }
-      done = true;
+      return;
     }
   }
-  if (!done) {
-  // ---- fp32 epilogue (f32 / accumulating outputs, unaligned output rows, the small-tile configs with a fused
-  // pre-activation / activation-backward / residual): stage the fp32 C tile through LDS (the operand buffers are free
-  // now) in 64-row passes, then every thread handles 8 consecutive n of one row: 16-byte coalesced traffic for the
+  // ---- epilogue: stage the fp32 C tile through LDS (the operand buffers are free now) in 64-row
+  // passes, then every thread handles 8 consecutive n of one row: 16-byte coalesced traffic for the
   // output, the saved pre-activation, the activation-backward source and the residual.
   float* sc = (float*)smem;                 // [64][CLD] f32
   constexpr int CLD = BN + 4;
   constexpr int PASSES = (BM + 63) / 64;
-  const bool vec_ok = (q.ldo & 7) == 0;
+  const bool vec_ok = (p.ldo & 7) == 0;
   const bool add_bias = zsplit == 0;
   float bia[8];
-  // A pass stages 64 tile rows: RPWM = 64/WM rows from EACH wve row-group, so that every wve deposits in every pass (the
-  // LDS store path has two halves, SIMDs {0,1} and {2,3}; a pass fed by the waves of one wme only ran it at half rate).
+  // A pass stages 64 tile rows: RPWM = 64/WM rows from EACH wave row-group, so that every wave deposits in every pass (the
+  // LDS store path has two halves, SIMDs {0,1} and {2,3}; a pass fed by the waves of one wm only ran it at half rate).
   // LDS row r of pass p holds tile row (r / RPWM) * TM + p * RPWM + r % RPWM.
   constexpr int RPWM = 64 / WM;
   static_assert((RPWM % 16 == 0 && TM % RPWM == 0) || BM < 64, "epilogue pass mapping");
-  auto tile_row = [&](int pass, int r) { return (r / RPWM) * TM + pass * RPWM + r % RPWM; };
+  const bool old_map = (p.debug & 256) != 0;      // A/B: one wave row-group per pass (the previous mapping)
+  auto tile_row = [&](int pass, int r) { return old_map ? pass * 64 + r : (r / RPWM) * TM + pass * RPWM + r % RPWM; };
 #pragma unroll
   for (int pass = 0; pass < PASSES; ++pass) {
 #pragma unroll
     for (int a = 0; a < FA; ++a) {
-      if ((a * 16) / RPWM == pass) {
+      if (!old_map && (a * 16) / RPWM == pass) {
 #pragma unroll
         for (int b = 0; b < FB; ++b)
-          *(f32x4*)(sc + (wme * RPWM + (a * 16) % RPWM + lme) * CLD + wne * TN + b * 16 + ln4e) = acc[b][a];
+          *(f32x4*)(sc + (wm * RPWM + (a * 16) % RPWM + lm) * CLD + wn * TN + b * 16 + ln4) = acc[b][a];
+      }
+      if (old_map && (wm * TM + a * 16) / 64 == pass) {
+#pragma unroll
+        for (int b = 0; b < FB; ++b)
+          *(f32x4*)(sc + (((wm * TM + a * 16) & 63) + lm) * CLD + wn * TN + b * 16 + ln4) = acc[b][a];
       }
     }
     __syncthreads();
-    if (q.out_mode >= 3) {
+    if constexpr (CE) {
+    if (p.out_mode >= 3) {
       // ---- fused LM-head cross-entropy epilogues (MFULL:1997 + TRAIN:287): the logits tile never leaves the chip.
       //   out_mode 3 (forward): per row of this tile, the online-softmax pair {max, sum exp(. - max)} over the tile's valid
       //                columns -> ce_part[m][tn]; the target column's logit -> ce_tl[m] (by the one tile that holds it)
       //   out_mode 4 (backward, logits recomputed): dlogit = (exp(logit - lse[m]) - [n == target[m]]) * coef[m] -> bf16 out
-      // (targets: q.dact_src as int64; forward: part = q.preact, tl = q.xsum; backward: {lse, coef} pairs = q.residual.)
+      // (targets: p.dact_src as int64; forward: part = p.preact, tl = p.xsum; backward: {lse, coef} pairs = p.residual.)
       constexpr int TPR = NTHR / 64, CPT = BN / TPR;          // threads per staged row, columns per thread
       static_assert(CPT % 8 == 0, "column groups of 8");
-      const int row = te / TPR, seg = te % TPR;
+      const int row = tid / TPR, seg = tid % TPR;
       const int m = m0 + tile_row(pass, row);
-      const bool mok = m < q.M;
+      const bool mok = m < p.M;
       const int nb = n0 + seg * CPT;
       const float* src = sc + row * CLD + seg * CPT;
-      const long long tgt = mok ? ((const long long*)q.dact_src)[m] - p.ce_col0 : -1;      // column inside this launch's N range
-      if (q.out_mode == 3) {
+      const long long tgt = mok ? ((const long long*)p.dact_src)[m] - p.ce_col0 : -1;      // column inside this launch's N range
+      if (p.out_mode == 3) {
         float mx = -INFINITY, sm = 0.f;
 #pragma unroll
         for (int j0 = 0; j0 < CPT; j0 += 4) {
@@ -816,10 +689,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int n = nb + j0 + j;
-            if (n < q.N) {
-              float v = v4[j] * q.alpha;
-              if (q.bias) v += q.bias[n];
-              if (n == tgt) q.xsum[m] = v;
+            if (n < p.N) {
+              float v = v4[j] * p.alpha;
+              if (p.bias) v += p.bias[n];
+              if (n == tgt) p.xsum[m] = v;
               const float nm = fmaxf(mx, v);
               sm = sm * __expf(mx - nm) + __expf(v - nm);
               mx = nm;
@@ -834,23 +707,23 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
           mx = nm;
         }
         if (seg == 0 && mok) {
-          float* part = (float*)q.preact + ((size_t)m * p.tiles_n + tn) * 2;
+          float* part = (float*)p.preact + ((size_t)m * p.tiles_n + tn) * 2;
           part[0] = mx; part[1] = sm;
         }
       } else if (mok) {
-        const float lse = ((const float*)q.residual)[2 * m], coef = ((const float*)q.residual)[2 * m + 1];
-        bf16_t* orow = (bf16_t*)q.out + (size_t)m * q.ldo;
+        const float lse = ((const float*)p.residual)[2 * m], coef = ((const float*)p.residual)[2 * m + 1];
+        bf16_t* orow = (bf16_t*)p.out + (size_t)m * p.ldo;
 #pragma unroll
         for (int j0 = 0; j0 < CPT; j0 += 8) {
           const int n = nb + j0;
-          if (n >= ((q.N + 7) & ~7)) continue;
+          if (n >= ((p.N + 7) & ~7)) continue;
           const f32x4 a4 = *(const f32x4*)(src + j0), b4 = *(const f32x4*)(src + j0 + 4);
           float d[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            float v = (j < 4 ? a4[j & 3] : b4[j & 3]) * q.alpha;
-            if (q.bias && n + j < q.N) v += q.bias[n + j];
-            d[j] = n + j < q.N ? (__expf(v - lse) - (n + j == tgt ? 1.f : 0.f)) * coef : 0.f;     // pad columns: exact zeros
+            float v = (j < 4 ? a4[j & 3] : b4[j & 3]) * p.alpha;
+            if (p.bias && n + j < p.N) v += p.bias[n + j];
+            d[j] = n + j < p.N ? (__expf(v - lse) - (n + j == tgt ? 1.f : 0.f)) * coef : 0.f;     // pad columns: exact zeros
           }
           store8bf(orow + n, d);                            // ldo % 8 == 0 and 16-byte rows are checked on the host
         }
@@ -858,22 +731,23 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
       __syncthreads();
       continue;
     }
-    if (q.out_mode == 2 && q.split_k > 1) {
-      // split-K accumulate: f32 atomics shaped as 256 contiguous bytes per wve-instruction (one row, 64
+    }
+    if (p.out_mode == 2 && p.split_k > 1) {
+      // split-K accumulate: f32 atomics shaped as 256 contiguous bytes per wave-instruction (one row, 64
       // consecutive columns) — the shape the memory-side atomic units run at full rate on
       constexpr int RPW = 64 / NWAVE;
 #pragma unroll 1
       for (int rr = 0; rr < RPW; ++rr) {
-        const int row = wve * RPW + rr;
+        const int row = wave * RPW + rr;
         const int m = m0 + tile_row(pass, row);
-        if (m >= q.M) continue;
+        if (m >= p.M) continue;
 #pragma unroll
         for (int h = 0; h < BN / 64; ++h) {
-          const int n = n0 + h * 64 + le;
-          if (n < q.N) {
-            float v = sc[row * CLD + h * 64 + le] * q.alpha;
-            if (q.bias && add_bias) v += q.bias[n];
-            atomicAdd((float*)q.out + (size_t)m * q.ldo + n, v);
+          const int n = n0 + h * 64 + lane;
+          if (n < p.N) {
+            float v = sc[row * CLD + h * 64 + lane] * p.alpha;
+            if (p.bias && add_bias) v += p.bias[n];
+            atomicAdd((float*)p.out + (size_t)m * p.ldo + n, v);
           }
         }
       }
@@ -887,13 +761,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
     constexpr int RPT = 64 * CPR / NTHR;      // chunks per thread per pass
     constexpr int RSTEP = NTHR / CPR;
     static_assert((64 * CPR) % NTHR == 0 && NTHR % CPR == 0, "epilogue chunk mapping");
-    const int c8 = (te % CPR) * 8, rbase = te / CPR;
+    const int c8 = (tid % CPR) * 8, rbase = tid / CPR;
     const int n = n0 + c8;
-    const bool fast = vec_ok && n + 8 <= q.N && (q.out_mode == 0 || (q.ldo & 3) == 0);
+    const bool fast = vec_ok && n + 8 <= p.N && (p.out_mode == 0 || (p.ldo & 3) == 0);
     if (fast) {
       if (pass == 0) {
-        if (q.bias && add_bias) {
-          const f32x4 b0 = *(const f32x4*)(q.bias + n), b1 = *(const f32x4*)(q.bias + n + 4);
+        if (p.bias && add_bias) {
+          const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
 #pragma unroll
           for (int j = 0; j < 4; ++j) { bia[j] = b0[j]; bia[4 + j] = b1[j]; }
         } else {
@@ -911,76 +785,62 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) { v[k][j] = v0[j]; v[k][4 + j] = v1[j]; }
         rraw[k] = (u32x4){0, 0, 0, 0}; draw[k] = (u32x4){0, 0, 0, 0};
-        if (m < q.M) {
-          const size_t off = (size_t)m * q.ldo + n;
-          if (q.residual) rraw[k] = *(const u32x4*)(q.residual + off);
-          if (q.dact_src) draw[k] = *(const u32x4*)(q.dact_src + off);
+        if (m < p.M) {
+          const size_t off = (size_t)m * p.ldo + n;
+          if (p.residual) rraw[k] = *(const u32x4*)(p.residual + off);
+          if (p.dact_src) draw[k] = *(const u32x4*)(p.dact_src + off);
         }
       }
 #pragma unroll
       for (int k = 0; k < RPT; ++k) {
         const int m = m0 + tile_row(pass, rbase + k * RSTEP);
-        if (m < q.M) epilogue8_vec(q, v[k], (size_t)m * q.ldo + n, bia, rraw[k], draw[k]);
+        if (m < p.M) epilogue8_vec(p, v[k], (size_t)m * p.ldo + n, bia, rraw[k], draw[k]);
       }
-    } else if (n < q.N) {
+    } else if (n < p.N) {
 #pragma unroll 1
       for (int k = 0; k < RPT; ++k) {
         const int row = rbase + k * RSTEP;
         const int m = m0 + tile_row(pass, row);
-        if (m < q.M) {
+        if (m < p.M) {
           float v[8];
           const f32x4 v0 = *(const f32x4*)(sc + row * CLD + c8), v1 = *(const f32x4*)(sc + row * CLD + c8 + 4);
 #pragma unroll
           for (int j = 0; j < 4; ++j) { v[j] = v0[j]; v[4 + j] = v1[j]; }
-          epilogue8(q, v, m, n, add_bias, vec_ok);
+          epilogue8(p, v, m, n, add_bias, vec_ok);
         }
       }
     }
     __syncthreads();
   }
-  }   // fp32 epilogue
-  if (!more) break;
-  if (!staged) {
-    lds_barrier();                   // every LDS read of this tile's epilogue has retired
-    prologue(wnx, wve, le);
-  }
-  wk = wnx; vb = vnext; pend = pend_next;
-  }   // work loop
 }
 
 
-template <int BM, int BN, int WM, int WN, int BKT, int NSTAGE, bool PIPE = false>
+template <int BM, int BN, int WM, int WN, int BKT, int NSTAGE, bool PIPE = false, bool CE = false>
 int launch_gemm(const GemmP& p0, bool xks, bool wks, int zsplits, hipStream_t s) {
   GemmP p = p0;
   p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
-  int nwg = p.tiles_m * p.tiles_n * zsplits;
-  if (PIPE && BKT == 32 && NSTAGE == 4 && !(p.debug & 64)) {
-    // persistent launch of the ping-pong configurations: one workgroup per CU walks the work items (gemm_kernel's work loop)
-    static int ncu = 0;
-    if (ncu == 0) {
-      int dev = 0; hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-      if (ncu <= 0) ncu = 256;
-      ncu = ncu / 8 * 8 > 0 ? ncu / 8 * 8 : 8;          // grid % 8 == 0 keeps a workgroup on one XCD's tile run
-    }
-    if (nwg > ncu) nwg = ncu;
-  }
+  const int nwg = p.tiles_m * p.tiles_n * zsplits;
   dim3 grid(nwg), block(64 * WM * WN);
-  constexpr size_t lds = (PIPE && BKT == 32 && NSTAGE == 4 ? 5 : NSTAGE) * (BM + BN) * BKT * 2;   // ping-pong: 5-slot ring
+  constexpr size_t lds = NSTAGE * (BM + BN) * BKT * 2;
   static_assert(lds >= 64 * (BN + 4) * 4, "epilogue staging must fit in the operand buffers");
 #define VAC_LAUNCH(XK, WK)                                                                            \
   do {                                                                                                \
-    auto kern = gemm_kernel<BM, BN, WM, WN, BKT, NSTAGE, PIPE, XK, WK>;                                                  \
+    auto kern = gemm_kernel<BM, BN, WM, WN, BKT, NSTAGE, PIPE, XK, WK, CE>;                                              \
     if (lds > 65536) {                                                                                \
       static bool once = false;                                                                       \
       if (!once) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; } \
     }                                                                                                 \
     hipLaunchKernelGGL(kern, grid, block, lds, s, p);                                                 \
   } while (0)
-  if (!xks && !wks) VAC_LAUNCH(false, false);
-  else if (!xks && wks) VAC_LAUNCH(false, true);
-  else if (xks && wks) VAC_LAUNCH(true, true);
-  else VAC_LAUNCH(true, false);
+  if constexpr (CE) {
+    if (xks || wks) { vacnic_set_error("gemm: the cross-entropy epilogues are built for the forward layout only"); return VACNIC_UNSUPPORTED; }
+    VAC_LAUNCH(false, false);
+  } else {
+    if (!xks && !wks) VAC_LAUNCH(false, false);
+    else if (!xks && wks) VAC_LAUNCH(false, true);
+    else if (xks && wks) VAC_LAUNCH(true, true);
+    else VAC_LAUNCH(true, false);
+  }
 #undef VAC_LAUNCH
   VLAUNCH_CHECK();
   return VACNIC_OK;
@@ -995,5 +855,6 @@ int launch_t64(const GemmP& p, bool xks, bool wks, int zsplits, hipStream_t s); 
 int launch_t260(const GemmP& p, bool xks, bool wks, int zsplits, hipStream_t s);   // A/B baselines kept for the ablations in profiles/
 int launch_t261(const GemmP& p, bool xks, bool wks, int zsplits, hipStream_t s);
 int launch_t262(const GemmP& p, bool xks, bool wks, int zsplits, hipStream_t s);
+int launch_t256ce(const GemmP& p, bool xks, bool wks, int zsplits, hipStream_t s); // 256x256 ping-pong + LM-head cross-entropy epilogues
 
 }  // namespace vacgemm
