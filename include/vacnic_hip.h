@@ -295,6 +295,28 @@ int vacnic_add_bf16(const void* a, const void* b, void* out, int64_t n, void* st
 int vacnic_beam_topk(const void* logits, const float* beam_scores, const int32_t* bans, int32_t n_ban, int32_t eos,
                      int32_t suppress_eos, int32_t forced_token, float* top_val, int32_t* top_idx, int64_t R, int64_t V,
                      int64_t ldl, int32_t K, int32_t logits_f32, void* stream);
+/*
+ * On-device beam-search bookkeeping: what transformers 4.18 BeamSearchScorer.process does on the host between
+ * two decoder steps (TRAIN:513-520 -> GenerationMixin.beam_search), plus the NoRepeatNGram ban lists of the next position —
+ * so the decode loop needs no device->host copy per token; the host reads this state once after the last position.
+ * R = B * nb rows.  seq[k]: int32 [R][Lmax] token histories (position t reads seq[(t) & 1]... see beam_step), ping-pong.
+ * Finished hypotheses are kept per batch item in list order: hyp_score f64 [B][nb] (= sum_logprobs / len^length_penalty),
+ * hyp_len int32 [B][nb], hyp_seq int32 [B][nb][Lmax], hyp_cnt int32 [B], hyp_worst f64 [B]; done int32 [B].
+ * vacnic_beam_init: histories = [start], beam scores = [0, -1e9, ...], empty lists.
+ * vacnic_beam_step(cur_len): consumes beam_topk's [R][K2] candidates of the position whose histories hold cur_len tokens
+ * (seq[(cur_len-1)&1]) and writes seq[cur_len&1], beam_scores (the next beam_topk's input), next_ids (last tokens, int64 [R]),
+ * src_idx (int64 [R]: the row each new beam continues = KV-cache reorder index) and bans (int32 [R][Lmax], -1 padded; NULL if
+ * no_repeat_ngram_size == 0).
+ */
+typedef struct {
+  int32_t* seq[2]; float* beam_scores; int32_t* done; int32_t* hyp_cnt; double* hyp_worst; double* hyp_score; int32_t* hyp_len;
+  int32_t* hyp_seq; int64_t* next_ids; int64_t* src_idx; int32_t* bans;
+  int64_t B, nb, Lmax, V, eos, pad, no_repeat_ngram_size, early_stopping;
+  float length_penalty;
+} vacnic_beam_state;
+int vacnic_beam_init(const vacnic_beam_state* st, int32_t start_token, void* stream);
+int vacnic_beam_step(const vacnic_beam_state* st, const float* top_val, const int32_t* top_idx, int32_t K2, int32_t cur_len,
+                     void* stream);
 /* dst[r] = src[idx[r]] for rows of row_bytes (multiple of 16): KV-cache beam reorder (_reorder_cache, MFULL:2066-2074). */
 int vacnic_gather_rows(const void* src, void* dst, const int64_t* idx, int64_t rows, int64_t row_bytes, void* stream);
 

@@ -405,7 +405,11 @@ def test_beam_search_kv_cache_matches_oracle_and_reference_golden():
                              name_ids=dev["names_art_ids"], name_mask=nmask, add_ner_ffn=True, **extra)
         want = O.beam_search_decode(sd, cfg, src, omask, img, nb, 12, lp, forced_eos_token_id=2, **extra, **okw)
         assert np.array_equal(want.numpy(), gold[f"seq{i}"]), (i, want.tolist(), gold[f"seq{i}"].tolist())
-        assert torch.equal(got.cpu(), want), (i, got.tolist(), want.tolist())
+        assert torch.equal(got.cpu(), want), (i, got.tolist(), want.tolist())      # default: on-device beam bookkeeping
+        host = model.generate(input_ids=dev["article_ids"], attention_mask=mask, num_beams=nb, max_length=12, length_penalty=lp,
+                              image_features=img.cuda(), face_features=dev["face_emb"], face_mask=K.face_mask(dev["face_emb"]),
+                              name_ids=dev["names_art_ids"], name_mask=nmask, add_ner_ffn=True, device_beams=False, **extra)
+        assert torch.equal(host.cpu(), want), (i, "host-side scorer", host.tolist(), want.tolist())
         # same shape again: every position is now captured as a hipGraph (2nd call) and replayed (3rd call)
         for rep in range(2):
             again = model.generate(input_ids=dev["article_ids"], attention_mask=mask, num_beams=nb, max_length=12, length_penalty=lp,

@@ -105,6 +105,12 @@ LmheadCeArgs = _struct("vacnic_lmhead_ce_args", [
     ("h", vp), ("emb", vp), ("bias", vp), ("targets", vp), ("part", vp), ("tl", vp), ("row_lse", vp), ("loss_sum", vp), ("count", vp),
     ("R", i64), ("V", i64), ("D", i64), ("ldh", i64), ("lde", i64), ("part_tiles", i64), ("ignore_index", i64)])
 
+BeamState = _struct("vacnic_beam_state", [
+    ("seq0", vp), ("seq1", vp), ("beam_scores", vp), ("done", vp), ("hyp_cnt", vp), ("hyp_worst", vp), ("hyp_score", vp), ("hyp_len", vp),
+    ("hyp_seq", vp), ("next_ids", vp), ("src_idx", vp), ("bans", vp),
+    ("B", i64), ("nb", i64), ("Lmax", i64), ("V", i64), ("eos", i64), ("pad", i64), ("no_repeat_ngram_size", i64), ("early_stopping", i64),
+    ("length_penalty", f32)])
+
 AdamwArgs = _struct("vacnic_adamw_args", [
     ("p", vp), ("g", vp), ("m", vp), ("v", vp), ("p_bf16", vp), ("hyper", vp),
     ("n", i64), ("beta1", f32), ("beta2", f32), ("eps", f32), ("weight_decay", f32), ("grad_scale", f32),
@@ -144,6 +150,8 @@ _PLAIN_FNS = {
     "vacnic_lmhead_ce_rowp": [vp, vp, vp, vp, f32, vp, i64, i64, vp],
     "vacnic_lmhead_ce_dlogits": [C.POINTER(LmheadCeArgs), i64, i64, vp, i64, vp, vp],
     "vacnic_zero_bytes": [vp, i64, vp],
+    "vacnic_beam_init": [C.POINTER(BeamState), i32, vp],
+    "vacnic_beam_step": [C.POINTER(BeamState), vp, vp, i32, i32, vp],
 }
 EXPORTED = sorted(list(_STRUCT_FNS) + list(_PLAIN_FNS) + ["vacnic_last_error_string", "vacnic_version"])
 

@@ -238,6 +238,176 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const char* __restrict
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// On-device beam-search bookkeeping: BeamSearchScorer.process of transformers 4.18 (the n-best lists,
+// EOS handling, done flags) + the NoRepeatNGram ban lists for the NEXT position, one wave per batch item.  With this the
+// decode loop has no device->host copy per token; the host reads the state once at the end (finalize).
+// State (all per session, device memory):
+//   seq_in / seq_out  int32 [R][Lmax]   token histories, ping-pong per position
+//   beam_scores       f32   [R]         running sum of log-probs (also the input of the next beam_topk)
+//   done              int32 [B];  hyp_cnt int32 [B];  hyp_worst f64 [B]
+//   hyp_score f64 [B][nb], hyp_len int32 [B][nb], hyp_seq int32 [B][nb][Lmax]      finished hypotheses, in list order
+// Outputs for the next position: next_ids int64 [R] (last tokens), src_idx int64 [R] (beam each new row continues: the
+// KV-cache reorder index), bans int32 [R][Lmax] (-1 padded).
+struct BeamP {
+  const float* top_val; const int32_t* top_idx;      // [R][K2] from beam_topk (scores include the beam score)
+  const int32_t* seq_in; int32_t* seq_out;
+  float* beam_scores; int32_t* done; int32_t* hyp_cnt; double* hyp_worst; double* hyp_score; int32_t* hyp_len; int32_t* hyp_seq;
+  int64_t* next_ids; int64_t* src_idx; int32_t* bans;
+  int nb, K2, Lmax, cur_len, V, eos, pad, ngram, early;
+  float length_penalty;
+};
+
+__global__ __launch_bounds__(64) void beam_step_kernel(BeamP p) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int nb = p.nb, K2 = p.K2, L = p.Lmax, cur = p.cur_len;
+  __shared__ float cs[64]; __shared__ int cj[64], ct[64];          // the group's top-2nb candidates, in rank order
+  __shared__ float nsc[32]; __shared__ int ntok[32], nsrc[32];      // the nb continuing beams
+  __shared__ int hyp_from[288]; __shared__ int hyp_slot[288]; __shared__ int n_hyp_copy;   // <= nb adds x (nb - 1 shifts + 1) per position
+  __shared__ int is_done, nsel_s;
+  if (lane == 0) { n_hyp_copy = 0; is_done = p.done[b]; nsel_s = 0; }
+  __syncthreads();
+  if (!is_done) {
+    // ---- merge the per-beam top-2nb lists: order (score desc, beam * V + token asc), keep 2nb.  Every lane owns up to two
+    // candidates; each round is a wave-wide arg-best by shuffles (a serial scan by one lane over global memory cost ~0.8 ms).
+    const int ncand = nb * K2;
+    float v0 = 0.f, v1 = 0.f; long long k0 = 0, k1 = 0; int t0 = -1, t1 = -1;
+    if (lane < ncand) { t0 = p.top_idx[(size_t)b * ncand + lane]; v0 = p.top_val[(size_t)b * ncand + lane]; k0 = (long long)(lane / K2) * p.V + t0; }
+    if (lane + 64 < ncand) { t1 = p.top_idx[(size_t)b * ncand + lane + 64]; v1 = p.top_val[(size_t)b * ncand + lane + 64]; k1 = (long long)((lane + 64) / K2) * p.V + t1; }
+    bool u0 = t0 < 0, u1 = t1 < 0;
+    for (int r = 0; r < K2; ++r) {
+      // this lane's best unused candidate
+      int bi = -1; float bv = 0.f; long long bk = 0;
+      if (!u0) { bi = lane; bv = v0; bk = k0; }
+      if (!u1 && (bi < 0 || v1 > bv || (v1 == bv && k1 < bk))) { bi = lane + 64; bv = v1; bk = k1; }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const int oi = __shfl_xor(bi, o, 64); const float ov = __shfl_xor(bv, o, 64);
+        const long long ok = ((long long)__shfl_xor((int)(bk >> 32), o, 64) << 32) | (unsigned)__shfl_xor((int)(bk & 0xffffffffLL), o, 64);
+        if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && ok < bk))) { bi = oi; bv = ov; bk = ok; }
+      }
+      if (bi < 0) break;                                    // wave-uniform
+      if (bi == lane) u0 = true;
+      if (bi == lane + 64) u1 = true;
+      if (lane == 0) { cs[r] = bv; cj[r] = bi / K2; ct[r] = (int)(bk - (long long)(bi / K2) * p.V); nsel_s = r + 1; }
+    }
+  }
+  __syncthreads();
+  if (lane == 0) {
+    if (!is_done) {
+      const int nsel = nsel_s;
+      // ---- BeamSearchScorer.process: EOS candidates within the first nb ranks finish a hypothesis, the rest continue
+      const double lenpow = pow((double)cur, (double)p.length_penalty);
+      int cnt = p.hyp_cnt[b]; double worst = p.hyp_worst[b];
+      int nch = 0;
+      for (int r = 0; r < nsel && nch < nb; ++r) {
+        if (ct[r] == p.eos) {
+          if (r >= nb) continue;
+          const double score = (double)cs[r] / lenpow;
+          if (cnt < nb || score > worst) {                                  // _BeamHyps.add
+            int slot = cnt;
+            if (cnt == nb) {
+              // list full: append, then drop the lowest score (lowest index among ties) -> compact in list order
+              int lo = 0;
+              for (int i = 1; i < nb; ++i) if (p.hyp_score[(size_t)b * nb + i] < p.hyp_score[(size_t)b * nb + lo]) lo = i;
+              const bool drop_new = score < p.hyp_score[(size_t)b * nb + lo];     // cannot happen (score > worst), kept for symmetry
+              if (!drop_new) {
+                for (int i = lo; i + 1 < nb; ++i) {
+                  p.hyp_score[(size_t)b * nb + i] = p.hyp_score[(size_t)b * nb + i + 1];
+                  p.hyp_len[(size_t)b * nb + i] = p.hyp_len[(size_t)b * nb + i + 1];
+                  // sequences of the shifted slots move too: queued as copies slot i+1 -> i (done by all lanes below, in order)
+                  hyp_from[n_hyp_copy] = -(i + 1) - 1; hyp_slot[n_hyp_copy] = i; ++n_hyp_copy;
+                }
+                slot = nb - 1;
+              } else {
+                slot = -1;
+              }
+            }
+            if (slot >= 0) {
+              p.hyp_score[(size_t)b * nb + slot] = score;
+              p.hyp_len[(size_t)b * nb + slot] = cur;
+              hyp_from[n_hyp_copy] = b * nb + cj[r]; hyp_slot[n_hyp_copy] = slot; ++n_hyp_copy;      // copy seq_in[row] -> hyp_seq[slot]
+              if (cnt < nb) ++cnt;
+              // worst = lowest score on the list (HF keeps it incrementally; identical value)
+              worst = p.hyp_score[(size_t)b * nb];
+              for (int i = 1; i < cnt; ++i) worst = fmin(worst, p.hyp_score[(size_t)b * nb + i]);
+            }
+          }
+        } else {
+          nsc[nch] = cs[r]; ntok[nch] = ct[r]; nsrc[nch] = b * nb + cj[r]; ++nch;
+        }
+      }
+      p.hyp_cnt[b] = cnt; p.hyp_worst[b] = worst;
+      // is_done(best_sum_logprobs = best candidate of the group, cur_len)
+      bool dn = false;
+      if (cnt >= nb) dn = p.early ? true : (worst >= (double)cs[0] / lenpow);
+      if (dn) p.done[b] = 1;
+      for (; nch < nb; ++nch) { nsc[nch] = -1e9f; ntok[nch] = p.pad; nsrc[nch] = b * nb; }       // cannot happen with 2nb candidates
+    } else {
+      for (int j = 0; j < nb; ++j) { nsc[j] = 0.f; ntok[j] = p.pad; nsrc[j] = b * nb; }           // finished batch: padded along
+    }
+  }
+  __syncthreads();
+  // ---- finished-hypothesis sequence moves, in the order they were queued (a shift reads a slot a later entry overwrites)
+  for (int c = 0; c < n_hyp_copy; ++c) {
+    const int from = hyp_from[c], slot = hyp_slot[c];
+    const int32_t* src = from < 0 ? p.hyp_seq + ((size_t)b * nb + (-from - 1)) * L : p.seq_in + (size_t)from * L;
+    int32_t* dst = p.hyp_seq + ((size_t)b * nb + slot) * L;
+    int32_t tmp[8];                                     // L <= 512
+    int n = 0;
+    for (int i = lane; i < L; i += 64) tmp[n++] = src[i];
+    __syncthreads();
+    n = 0;
+    for (int i = lane; i < L; i += 64) dst[i] = tmp[n++];
+    __syncthreads();
+  }
+  // ---- the nb continuing beams: history + new token, score, source row, last token; then their NoRepeatNGram bans
+  for (int j = 0; j < nb; ++j) {
+    const int row = b * nb + j;
+    const int32_t* src = p.seq_in + (size_t)nsrc[j] * L;
+    int32_t* dst = p.seq_out + (size_t)row * L;
+    for (int i = lane; i < L; i += 64) dst[i] = i < cur ? src[i] : (i == cur ? ntok[j] : p.pad);
+    if (lane == 0) {
+      p.beam_scores[row] = nsc[j];
+      p.next_ids[row] = ntok[j];
+      p.src_idx[row] = nsrc[j];
+    }
+  }
+  __syncthreads();
+  if (p.bans) {
+    const int n = p.ngram, len = cur + 1;                 // histories now hold cur + 1 tokens
+    __shared__ int nban;
+    for (int j = 0; j < nb; ++j) {
+      const int row = b * nb + j;
+      const int32_t* sq = p.seq_out + (size_t)row * L;
+      int32_t* bn = p.bans + (size_t)row * L;
+      if (lane == 0) nban = 0;
+      __syncthreads();
+      if (n > 0 && len + 1 >= n && !is_done) {
+        for (int i = lane; i <= len - n; i += 64) {
+          bool match = true;
+          for (int k = 0; k < n - 1; ++k) match = match && sq[i + k] == sq[len - (n - 1) + k];
+          if (match) bn[atomicAdd(&nban, 1)] = sq[i + n - 1];
+        }
+      }
+      __syncthreads();
+      for (int i = nban + lane; i < L; i += 64) bn[i] = -1;
+      __syncthreads();
+    }
+  }
+}
+
+__global__ void beam_init_kernel(int32_t* seq, float* beam_scores, int32_t* done, int32_t* hyp_cnt, double* hyp_worst, int64_t* next_ids,
+                                 int32_t* bans, int R, int nb, int L, int start, int pad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < R * L) {
+    seq[i] = (i % L) == 0 ? start : pad;
+    if (bans) bans[i] = -1;
+  }
+  if (i < R) { beam_scores[i] = (i % nb) == 0 ? 0.f : -1e9f; next_ids[i] = start; }
+  if (i < R / nb) { done[i] = 0; hyp_cnt[i] = 0; hyp_worst[i] = 1e9; }
+}
 }  // namespace
 
 extern "C" int vacnic_beam_topk(const void* logits, const float* beam_scores, const int32_t* bans, int32_t n_ban, int32_t eos,
@@ -277,6 +447,36 @@ extern "C" int vacnic_gather_rows(const void* src, void* dst, const int64_t* idx
   if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const char*)src, (char*)dst, idx,
                      (long)rows, chunks);
+  VLAUNCH_CHECK();
+  return VACNIC_OK;
+}
+
+extern "C" int vacnic_beam_init(const vacnic_beam_state* st, int32_t start_token, void* stream) {
+  VCHECK(st && st->seq[0] && st->beam_scores && st->done && st->hyp_cnt && st->hyp_worst && st->next_ids, VACNIC_BAD_SHAPE, "beam_init: null state");
+  VCHECK(st->B > 0 && st->nb > 0 && st->Lmax > 0, VACNIC_BAD_SHAPE, "beam_init: bad sizes");
+  const int R = (int)(st->B * st->nb);
+  const int n = R * (int)st->Lmax;
+  hipLaunchKernelGGL(beam_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, st->seq[0], st->beam_scores,
+                     st->done, st->hyp_cnt, st->hyp_worst, st->next_ids, st->bans, R, (int)st->nb, (int)st->Lmax, start_token, (int)st->pad);
+  VLAUNCH_CHECK();
+  return VACNIC_OK;
+}
+
+extern "C" int vacnic_beam_step(const vacnic_beam_state* st, const float* top_val, const int32_t* top_idx, int32_t K2, int32_t cur_len,
+                                void* stream) {
+  VCHECK(st && top_val && top_idx && st->seq[0] && st->seq[1] && st->hyp_score && st->hyp_len && st->hyp_seq && st->src_idx,
+         VACNIC_BAD_SHAPE, "beam_step: null operand");
+  VCHECK(st->nb >= 1 && st->nb <= 16 && K2 >= 1 && K2 <= 64 && st->nb * K2 <= 128, VACNIC_UNSUPPORTED, "beam_step: nb <= 16, K2 <= 64, nb*K2 <= 128");
+  VCHECK(cur_len >= 1 && cur_len < st->Lmax && st->Lmax <= 512, VACNIC_BAD_SHAPE, "beam_step: cur_len %d outside [1, Lmax=%ld) or Lmax > 512",
+         (int)cur_len, (long)st->Lmax);
+  BeamP p;
+  p.top_val = top_val; p.top_idx = top_idx;
+  p.seq_in = st->seq[(cur_len - 1) & 1]; p.seq_out = st->seq[cur_len & 1];
+  p.beam_scores = st->beam_scores; p.done = st->done; p.hyp_cnt = st->hyp_cnt; p.hyp_worst = st->hyp_worst; p.hyp_score = st->hyp_score;
+  p.hyp_len = st->hyp_len; p.hyp_seq = st->hyp_seq; p.next_ids = st->next_ids; p.src_idx = st->src_idx; p.bans = st->bans;
+  p.nb = (int)st->nb; p.K2 = K2; p.Lmax = (int)st->Lmax; p.cur_len = cur_len; p.V = (int)st->V; p.eos = (int)st->eos; p.pad = (int)st->pad;
+  p.ngram = (int)st->no_repeat_ngram_size; p.early = (int)st->early_stopping; p.length_penalty = st->length_penalty;
+  hipLaunchKernelGGL(beam_step_kernel, dim3((unsigned)st->B), dim3(64), 0, (hipStream_t)stream, p);
   VLAUNCH_CHECK();
   return VACNIC_OK;
 }

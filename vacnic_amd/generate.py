@@ -7,8 +7,10 @@ What runs where
     attention over the cache (self) and over the per-layer cross K/V computed once from the encoder states, FFN,
     LM head, log-softmax + logits processors + top-2k (`beam_topk`), cache reorder for all layers in one launch
     (`gather_rows`; _reorder_cache MFULL:2066-2074 — cross K/V are never reordered, as in the reference).
-  * host: the n-best bookkeeping of transformers 4.18 BeamSearchScorer (a few dozen scalars per step).  This costs one
-    device->host copy of [B*beams, 2*beams] candidates per token; moving it on device is the "next" item of SURVEY §8f-1.
+  * beam bookkeeping (transformers 4.18 BeamSearchScorer.process: n-best lists, EOS handling, done flags) and the
+    NoRepeatNGram ban lists: `vacnic_beam_step`, one wave per batch item, in the same per-position graph; the
+    host reads the state ONCE after the last position (and polls the done flags every 8th position to stop early).
+    `device_beams=False` keeps the host-side scorer (one device->host copy of the [B*beams, 2*beams] candidates per token).
 
 The cache is preallocated ([layers, B*beams, max_length, 2d] bf16, k|v interleaved per row) instead of the reference's
 per-step torch.cat (MFULL:489-492).
@@ -153,6 +155,60 @@ class DecodeSession:
         self.h_bans = torch.full((R, max_length), -1, dtype=torch.int32).pin_memory() if ngram > 0 else None
         self.graphs, self.outs, self.pool = {}, {}, None
         self.captions = 0
+        self.beam = None                  # device-side beam bookkeeping (enable_device_beams)
+
+    def enable_device_beams(self, B, length_penalty, early_stopping, pad):
+        """state of vacnic_beam_step: token histories, n-best lists and done flags live in HBM; the step kernel
+        also writes this session's next-token / beam-score / reorder-index / ban buffers, so a position needs no host round trip."""
+        from . import _lib
+        dev = self.ids_s.device
+        R, nb, L = self.R, self.nb, self.max_length
+        i32 = dict(device=dev, dtype=torch.int32)
+        if self.bans_s is None and self.ngram > 0:
+            self.bans_s = torch.full((R, L), -1, **i32)
+        self.seq = torch.zeros((2, R, L), **i32)
+        self.done_d = torch.zeros(B, **i32)
+        self.hyp_cnt = torch.zeros(B, **i32)
+        self.hyp_worst = torch.zeros(B, device=dev, dtype=torch.float64)
+        self.hyp_score = torch.zeros((B, nb), device=dev, dtype=torch.float64)
+        self.hyp_len = torch.zeros((B, nb), **i32)
+        self.hyp_seq = torch.zeros((B, nb, L), **i32)
+        self.B, self.lp, self.early, self.pad = B, length_penalty, early_stopping, pad
+        self.beam = _lib.BeamState(seq0=self.seq[0].data_ptr(), seq1=self.seq[1].data_ptr(), beam_scores=self.scores_s.data_ptr(),
+                                   done=self.done_d.data_ptr(), hyp_cnt=self.hyp_cnt.data_ptr(), hyp_worst=self.hyp_worst.data_ptr(),
+                                   hyp_score=self.hyp_score.data_ptr(), hyp_len=self.hyp_len.data_ptr(), hyp_seq=self.hyp_seq.data_ptr(),
+                                   next_ids=self.ids_s.data_ptr(), src_idx=self.src_s.data_ptr(),
+                                   bans=self.bans_s.data_ptr() if self.bans_s is not None else None,
+                                   B=B, nb=nb, Lmax=L, V=self.model.V, eos=self.eos, pad=pad, no_repeat_ngram_size=self.ngram,
+                                   early_stopping=int(bool(early_stopping)), length_penalty=float(length_penalty))
+
+    def run_device(self, start, use_graphs):
+        """the whole beam search of one batch without per-token host synchronisation; returns the host-side tensors finalize needs."""
+        from . import _lib
+        st = K._stream()
+        _lib.check(_lib.lib.vacnic_beam_init(_lib.C.byref(self.beam), int(start), st))
+        steps = 0
+        for t in range(self.max_length - 1):
+            if use_graphs and self.captions > 0:
+                g = self.graphs.get(t)
+                if g is None:
+                    g = torch.cuda.CUDAGraph()
+                    torch.cuda.synchronize()
+                    with torch.cuda.graph(g, pool=self.pool):
+                        self.body(t)
+                    if self.pool is None:
+                        self.pool = g.pool()
+                    self.graphs[t] = g
+                g.replay()
+            else:
+                self.body(t)
+            steps = t + 1
+            if t % 8 == 7 and t + 1 < self.max_length - 1 and bool(self.done_d.all().item()):     # one tiny sync every 8 positions
+                break
+        cur_len = steps + 1                                  # tokens in every live history
+        seqs = self.seq[steps & 1].cpu()
+        return (cur_len, seqs, self.scores_s.cpu(), self.done_d.cpu(), self.hyp_cnt.cpu(), self.hyp_score.cpu(), self.hyp_len.cpu(),
+                self.hyp_seq.cpu())
 
     def body(self, t):
         if self.nb > 1 and t > 0:
@@ -163,8 +219,12 @@ class DecodeSession:
         if self.forced_bos is not None and cur_len == 1:             # ForcedBOSTokenLogitsProcessor (runs before ForcedEOS in HF)
             forced = self.forced_bos if forced < 0 else forced
         V = self.model.V
-        return K.beam_topk(logits, V, min(2 * self.nb, V), beam_scores=self.scores_s, bans=self.bans_s, eos=self.eos,
-                           suppress_eos=cur_len < self.min_length, forced_token=forced)
+        tv, ti = K.beam_topk(logits, V, min(2 * self.nb, V), beam_scores=self.scores_s, bans=self.bans_s, eos=self.eos,
+                             suppress_eos=cur_len < self.min_length, forced_token=forced)
+        if self.beam is not None:
+            from . import _lib
+            _lib.check(_lib.lib.vacnic_beam_step(_lib.C.byref(self.beam), tv.data_ptr(), ti.data_ptr(), tv.shape[1], cur_len, K._stream()))
+        return tv, ti
 
     def step(self, t, last_tokens, scores, src, bans, use_graphs):
         """host lists in, (top values, top ids) on the host out — the one device->host sync of the position."""
@@ -201,7 +261,8 @@ class DecodeSession:
 @torch.no_grad()
 def generate(model, input_ids=None, attention_mask=None, num_beams=1, max_length=20, length_penalty=1.0, early_stopping=False,
              no_repeat_ngram_size=0, min_length=0, forced_eos_token_id="config", forced_bos_token_id=None, image_features=None,
-             face_features=None, face_mask=None, name_ids=None, name_mask=None, add_ner_ffn=True, use_graphs=True, **unused):
+             face_features=None, face_mask=None, name_ids=None, name_mask=None, add_ner_ffn=True, use_graphs=True, device_beams=True,
+             **unused):
     """GenerationMixin.generate(do_sample=False) semantics of transformers 4.18 for this model (greedy = 1 beam).
     Returns int64 [B, L] starting with decoder_start_token_id, padded with pad_token_id.
     Keyword defaults are the LIBRARY defaults; the defaults a hub checkpoint's config.json adds on top (what the reference's
@@ -223,13 +284,41 @@ def generate(model, input_ids=None, attention_mask=None, num_beams=1, max_length
                               name_mask=name_mask, face_features=face_features, face_mask=face_mask, add_ner_ffn=add_ner_ffn)
     enc_h = enc["last_hidden_state"]
     S, d = enc_h.shape[1], enc_h.shape[2]
-    key = (R, S, max_length, nb, no_repeat_ngram_size, min_length, forced_eos_token_id, forced_bos_token_id)
+    device_beams = bool(device_beams) and nb <= 16 and 2 * nb * nb <= 128 and max_length <= 512
+    key = (R, S, max_length, nb, no_repeat_ngram_size, min_length, forced_eos_token_id, forced_bos_token_id,
+           (float(length_penalty), bool(early_stopping)) if device_beams else None)
     sessions = model.__dict__.setdefault("_decode_sessions", {})
     ses = sessions.get(key)
     if ses is None:
         ses = sessions[key] = DecodeSession(model, R, S, max_length, nb, no_repeat_ngram_size, min_length, forced_eos_token_id, eos,
                                             forced_bos=forced_bos_token_id)
+        if device_beams:
+            ses.enable_device_beams(B, length_penalty, early_stopping, pad)
     ses.dec.begin(enc_h, mask_u8, nb)
+    if device_beams:
+        # on-device bookkeeping: the positions are enqueued back to back; ONE device->host copy of the final state
+        cur_len, seqs_t, scores_t, done_t, hcnt, hscore, hlen, hseq = ses.run_device(start, use_graphs)
+        ses.captions += 1
+        out = []
+        for b in range(B):
+            hy = _BeamHyps(nb, length_penalty, early_stopping)
+            for i in range(int(hcnt[b])):
+                hy.beams.append((float(hscore[b, i]), hseq[b, i, :int(hlen[b, i])].tolist()))
+            if hy.beams:
+                hy.worst = min(sc for sc, _ in hy.beams)
+            if not bool(done_t[b]):
+                for j in range(nb):                       # BeamSearchScorer.finalize: open beams join the n-best list
+                    hy.add(seqs_t[b * nb + j, :cur_len].tolist(), float(scores_t[b * nb + j]))
+            out.append(sorted(hy.beams, key=lambda x: x[0])[-1][1])
+        L = min(max(len(o) for o in out) + 1, max_length)
+        res = torch.full((B, L), pad, dtype=torch.long)
+        for b, o in enumerate(out):
+            res[b, :len(o)] = torch.tensor(o)
+            if len(o) < L:
+                res[b, len(o)] = eos
+        if was_training:
+            model.train()
+        return res.to(enc_h.device)
 
     seqs = [[start] for _ in range(R)]
     beam_scores = [0.0 if (r % nb) == 0 else -1e9 for r in range(R)]
