@@ -374,8 +374,9 @@ def main():
                      "TT": "gemm_kernel<true,true> (wgrad)", "TN": "gemm_kernel<true,false>"}
             traffic = None
             try:        # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes of this same command
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_hbm_traffic.json")))["kernels"]
-                tag = {"NN": "false, false>", "NT": "false, true>", "TT": "true, true>", "TN": "true, false>"}[kind]
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_hbm_traffic.json")))["kernels"]
+                # gemm_kernel<BM, BN, WM, WN, BKT, NSTAGE, PIPE, XKS, WKS, CE>: the last three flags name the layout
+                tag = {"NN": ", false, false, false>", "NT": ", false, true, false>", "TT": ", true, true, false>", "TN": ", true, false, false>"}[kind]
                 sel = [v for k, v in pm.items() if "gemm_kernel" in k and tag in k]
                 if sel:
                     traffic = round(sum(v["launches"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) for v in sel) / sum(v["launches"] for v in sel))
@@ -383,7 +384,7 @@ def main():
                 traffic = None
             roof = {"bound": "mfma", "kernel": names[kind], "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                    "traffic_note": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r1_pmc_hbm_traffic.json)", "launches": n,
+                    "traffic_note": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r2_pmc_hbm_traffic.json)", "launches": n,
                     "flop_per_launch": round(fl / n),
                     "avg_launch_us": round(sec / n * 1e6, 2),
                     "all_gemm": {k: {"TFLOP/s": round(v[0] / v[1] / 1e12, 1), "ms": round(v[1] * 1e3, 2), "launches": v[2]} for k, v in agg.items()}}
