@@ -248,7 +248,20 @@ def self_launch(a):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     log(f"--gpus {a.gpus} without WORLD_SIZE: launching {a.gpus} ranks via torch.distributed.run (port {port})")
-    return subprocess.call(cmd, env=env)
+    # stdout must carry exactly ONE line (rank 0's JSON): whatever else the ranks or the communication library print there
+    # (gloo announces its peers on stdout) goes to stderr
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    result = None
+    for line in proc.stdout:
+        if line.startswith("{") and '"metric"' in line:
+            result = line
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if result is not None:
+        sys.stdout.write(result)
+        sys.stdout.flush()
+    return rc if rc != 0 or result is not None else 1
 
 
 def main():
