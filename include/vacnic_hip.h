@@ -78,6 +78,22 @@ typedef struct {
 int vacnic_gemm_bf16(const vacnic_gemm_args* a, void* stream);
 
 /*
+ * Single-token decoder step: y = epi( LayerNorm(x + residual) . W^T + bias ), M <= 8 rows (beams x batch), K = d_model <= 1024.
+ * The post-LN of one decoder sub-block (MFULL:836,859,880: residual add + LayerNorm, eval mode: no dropout) fused as a prologue
+ * into the first projection of the next sub-block (q/k/v, cross-attention q, fc1, lm_head); ln_out (bf16 [M][K], optional)
+ * receives the normalised rows — the next sub-block's residual.  Bit-identical to vacnic_add_ln_fwd followed by
+ * vacnic_gemm_bf16 (skinny kernel).  x / residual rows are contiguous (stride K); act as in vacnic_gemm_bf16; out_mode 0 bf16, 1 f32.
+ */
+typedef struct {
+  const void* x; const void* residual; const float* gamma; const float* beta; void* ln_out;
+  const void* w; const float* bias; void* out;
+  int64_t M, N, K, ldw, ldo;
+  int32_t act, out_mode;
+  float eps;
+} vacnic_gemv_ln_args;
+int vacnic_gemv_ln_bf16(const vacnic_gemv_ln_args* a, void* stream);
+
+/*
  * Fused attention core (replaces bmm -> +mask -> softmax -> bmm of BartAttention.forward,
  * MFULL:509-548, and nn.MultiheadAttention inside the CLIP ViT).  head_dim must be 64.
  *   q: [B][Tq][..] bf16, row stride ldq, head h at column offset h*64; likewise k, v (rows Tk).

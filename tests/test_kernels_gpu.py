@@ -580,3 +580,25 @@ def test_gemm_skinny_rows(K, M, N, K_):
     K.gemm(x, w, M, N, K_, bias=b, out=out, ldo=ldo, out_mode=1)
     close(out[:, :N], ref, 1e-3, 2e-3 * ref.abs().max().item(), "skinny fp32 out")
     assert out[:, N:].abs().max().item() == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K_,act,f32", [(5, 3072, 1024, None, False), (5, 1024, 1024, None, False), (8, 4096, 1024, "gelu", False),
+                                             (1, 50267, 1024, None, True), (3, 1000, 768, None, False), (5, 520, 512, "tanh", False)])
+def test_gemv_ln_prologue_is_bit_identical_to_add_ln_then_skinny_gemm(K, M, N, K_, act, f32):
+    """single-token decoder: residual add + LayerNorm fused as a prologue into the consuming projection."""
+    x = rnd(M, K_, seed=1); res = rnd(M, K_, seed=2)
+    g = rnd(K_, dtype=torch.float32, seed=3) * 0.5 + 1.0; b = rnd(K_, dtype=torch.float32, seed=4) * 0.1
+    w = rnd(N, K_, scale=0.05, seed=5); bias = rnd(N, dtype=torch.float32, seed=6)
+    ld = (N + 31) // 32 * 32
+    h_ref, _, _ = K.add_ln_fwd(x.view(M, 1, K_), res.view(M, 1, K_), g, b, need_stats=False)
+    want = torch.zeros(M, ld, device="cuda", dtype=torch.float32 if f32 else torch.bfloat16)
+    K.gemm(h_ref.view(M, K_), w, M, N, K_, bias=bias, out=want, ldo=ld, act=act, out_mode=1 if f32 else 0, tile_hint=8)
+    got = torch.zeros_like(want)
+    hn = torch.empty(M, K_, device="cuda", dtype=torch.bfloat16)
+    K.gemv_ln(x, res, g, b, w, M, N, K_, bias=bias, out=got, ln_out=hn, ldo=ld, act=act, out_mode=1 if f32 else 0)
+    assert torch.equal(hn, h_ref.view(M, K_)), "normalised rows"
+    assert torch.equal(got, want), (got.float() - want.float()).abs().max().item()
+    ref = torch.nn.functional.layer_norm(x.float() + res.float(), (K_,), g, b) @ w.float().t() + bias
+    f = {None: lambda t: t, "gelu": torch.nn.functional.gelu, "tanh": torch.tanh}[act]
+    close(got[:, :N], f(ref), 2e-2, 2e-2, "vs fp32")

@@ -39,6 +39,10 @@ GemmArgs = _struct("vacnic_gemm_args", [
     ("M", i64), ("N", i64), ("K", i64), ("ldx", i64), ("ldw", i64), ("ldo", i64),
     ("x_kstrided", i32), ("w_kstrided", i32), ("act", i32), ("out_mode", i32), ("split_k", i32), ("alpha", f32), ("tile_hint", i32)])
 
+GemvLnArgs = _struct("vacnic_gemv_ln_args", [
+    ("x", vp), ("residual", vp), ("gamma", vp), ("beta", vp), ("ln_out", vp), ("w", vp), ("bias", vp), ("out", vp),
+    ("M", i64), ("N", i64), ("K", i64), ("ldw", i64), ("ldo", i64), ("act", i32), ("out_mode", i32), ("eps", f32)])
+
 AttnFwdArgs = _struct("vacnic_attn_fwd_args", [
     ("q", vp), ("k", vp), ("v", vp), ("out", vp), ("lse", vp), ("key_mask", vp),
     ("B", i64), ("H", i64), ("Tq", i64), ("Tk", i64),
@@ -119,7 +123,7 @@ AdamwArgs = _struct("vacnic_adamw_args", [
 # symbol -> argtypes.  EVERY function include/vacnic_hip.h declares must appear here
 # (tests/test_abi.py parses the header and checks both directions).
 _STRUCT_FNS = {
-    "vacnic_gemm_bf16": GemmArgs, "vacnic_attn_fwd": AttnFwdArgs, "vacnic_attn_bwd": AttnBwdArgs,
+    "vacnic_gemm_bf16": GemmArgs, "vacnic_gemv_ln_bf16": GemvLnArgs, "vacnic_attn_fwd": AttnFwdArgs, "vacnic_attn_bwd": AttnBwdArgs,
     "vacnic_add_ln_fwd": AddLnFwdArgs, "vacnic_add_ln_bwd": AddLnBwdArgs,
     "vacnic_embed_ln_fwd": EmbedLnFwdArgs, "vacnic_embed_ln_bwd": EmbedLnBwdArgs,
     "vacnic_ce_fwd": CeArgs, "vacnic_ce_bwd": CeArgs,

@@ -107,7 +107,173 @@ __global__ __launch_bounds__(64 * KW) void gemm_skinny_kernel(GemmP p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Skinny GEMM with a residual + LayerNorm PROLOGUE (single-token decoder): y = epi( LN(x + res) . W^T + b ), and the
+// normalised rows LN(x + res) are written once (by workgroup 0) because the next block needs them as ITS residual.
+// Replaces {add_ln_fwd, gemm_skinny} pairs of the decode step (36 of its 142 launches per token): every wave recomputes the
+// statistics of the <= 8 rows (10 KB from L2, two wave reductions per row) WHILE its weight loads — issued first, they do not
+// depend on x — are still in flight, so the prologue costs no latency of its own.  The arithmetic is add_ln_fwd_kernel's, in the
+// same order on the same lanes (chunk c = lane + 64 i, fp32 sums, wave butterfly), and the normalised values are rounded to
+// bf16 before the dot products exactly as if they had been stored and re-loaded: the logits are bit-identical to the
+// unfused chain.
+struct GemvLnP {
+  const bf16_t* x; const bf16_t* res; const float* gamma; const float* beta; bf16_t* ln_out;
+  const bf16_t* w; const float* bias; void* out;
+  int M, N, K, ldw, ldo, act, out_mode;
+  float eps;
+};
+
+template <int MR, int CW, int NCH>
+__global__ __launch_bounds__(64) void gemv_ln_kernel(GemvLnP p) {
+  const int lane = threadIdx.x & 63;
+  const int n0 = blockIdx.x * CW;
+  const int nchunk = p.K >> 3;
+  // 1. activations, residual and LayerNorm parameters FIRST, weights second: vmcnt retires loads in issue order, so the
+  //    statistics can start as soon as the (L2-resident) rows are back while the weight stream from HBM is still in flight
+  u32x4 xraw[MR][NCH], rraw[MR][NCH];
+#pragma unroll
+  for (int m = 0; m < MR; ++m)
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int ch = lane + 64 * i;
+      xraw[m][i] = (u32x4){0, 0, 0, 0}; rraw[m][i] = (u32x4){0, 0, 0, 0};
+      if (m < p.M && ch < nchunk) {
+        xraw[m][i] = *(const u32x4*)(p.x + (size_t)m * p.K + ch * 8);
+        rraw[m][i] = *(const u32x4*)(p.res + (size_t)m * p.K + ch * 8);
+      }
+    }
+  float gam[NCH][8], bet[NCH][8];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int ch = lane + 64 * i;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { gam[i][j] = 0.f; bet[i][j] = 0.f; }
+    if (ch < nchunk) {
+      const f32x4 g0 = *(const f32x4*)(p.gamma + ch * 8), g1 = *(const f32x4*)(p.gamma + ch * 8 + 4);
+      const f32x4 b0 = *(const f32x4*)(p.beta + ch * 8), b1 = *(const f32x4*)(p.beta + ch * 8 + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { gam[i][j] = g0[j]; gam[i][4 + j] = g1[j]; bet[i][j] = b0[j]; bet[i][4 + j] = b1[j]; }
+    }
+  }
+  u32x4 wraw[CW][NCH];
+#pragma unroll
+  for (int c = 0; c < CW; ++c)
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int ch = lane + 64 * i;
+      wraw[c][i] = (u32x4){0, 0, 0, 0};
+      if (ch < nchunk && n0 + c < p.N) wraw[c][i] = *(const u32x4*)(p.w + (size_t)(n0 + c) * p.ldw + ch * 8);
+    }
+  // 2. h = x + res, LayerNorm statistics per row (add_ln_fwd_kernel's order of operations)
+  float h[MR][NCH][8];
+#pragma unroll
+  for (int m = 0; m < MR; ++m) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int ch = lane + 64 * i;
+      if (m < p.M && ch < nchunk) {
+        float xv[8], rv[8];
+        unpack8bf(xraw[m][i], xv);
+        unpack8bf(rraw[m][i], rv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { xv[j] += rv[j]; h[m][i][j] = xv[j]; s += xv[j]; }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) h[m][i][j] = 0.f;
+      }
+    }
+    if (m < p.M) {
+      const float mean = wave_sum(s) / p.K;
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        if (lane + 64 * i < nchunk) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { const float d = h[m][i][j] - mean; q += d * d; }
+        }
+      }
+      const float rstd = rsqrtf(wave_sum(q) / p.K + p.eps);
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nchunk) {
+          float y[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) y[j] = (h[m][i][j] - mean) * rstd * gam[i][j] + bet[i][j];
+          const u32x4 packed = (u32x4){pack2bf(y[0], y[1]), pack2bf(y[2], y[3]), pack2bf(y[4], y[5]), pack2bf(y[6], y[7])};
+          if (blockIdx.x == 0 && p.ln_out) *(u32x4*)(p.ln_out + (size_t)m * p.K + ch * 8) = packed;
+          unpack8bf(packed, h[m][i]);                    // the bf16-rounded values, as the unfused chain would re-load them
+        }
+      }
+    }
+  }
+  // 3. dot products + the skinny kernel's reduce-scatter butterfly and epilogue
+  constexpr int NV = MR * CW;
+  float acc[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) acc[i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      float wv[8];
+      unpack8bf(wraw[c][i], wv);
+#pragma unroll
+      for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[m * CW + c] += h[m][i][j] * wv[j];
+    }
+  static_assert(NV == 32, "butterfly written for 32 values per lane");
+#define VAC_BFLY(OFF, HALF)                                                      \
+  {                                                                              \
+    const bool up = (lane & OFF) != 0;                                           \
+    _Pragma("unroll") for (int i = 0; i < HALF; ++i) {                           \
+      const float send = up ? acc[i] : acc[HALF + i];                            \
+      const float keep = up ? acc[HALF + i] : acc[i];                            \
+      acc[i] = keep + __shfl_xor(send, OFF, 64);                                 \
+    }                                                                            \
+  }
+  VAC_BFLY(32, 16) VAC_BFLY(16, 8) VAC_BFLY(8, 4) VAC_BFLY(4, 2) VAC_BFLY(2, 1)
+#undef VAC_BFLY
+  float v = acc[0] + __shfl_xor(acc[0], 1, 64);
+  const int idx = (((lane >> 5) & 1) << 4) | (((lane >> 4) & 1) << 3) | (((lane >> 3) & 1) << 2) | (((lane >> 2) & 1) << 1) | ((lane >> 1) & 1);
+  if ((lane & 1) == 0) {
+    const int m = idx / CW, c = idx % CW;
+    const int n = n0 + c;
+    if (m < p.M && n < p.N) {
+      if (p.bias) v += p.bias[n];
+      v = act_fwd(p.act, v);
+      const size_t off = (size_t)m * p.ldo + n;
+      if (p.out_mode == 0) ((bf16_t*)p.out)[off] = f2bf(v);
+      else ((float*)p.out)[off] = v;
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int vacnic_gemv_ln_bf16(const vacnic_gemv_ln_args* a, void* stream) {
+  VCHECK(a && a->x && a->residual && a->gamma && a->beta && a->w && a->out, VACNIC_BAD_SHAPE, "gemv_ln: null operand");
+  VCHECK(a->M >= 1 && a->M <= 8 && a->N > 0, VACNIC_UNSUPPORTED, "gemv_ln: 1 <= M <= 8 rows");
+  VCHECK(a->K > 0 && (a->K & 7) == 0 && a->K <= 1024, VACNIC_UNSUPPORTED, "gemv_ln: K %% 8 == 0 and K <= 1024 (one LayerNorm row per wave)");
+  VCHECK((a->ldw & 7) == 0 && a->ldw >= a->K && aligned16(a->x) && aligned16(a->residual) && aligned16(a->w), VACNIC_MISALIGNED,
+         "gemv_ln: 16-byte aligned operands, ldw %% 8 == 0");
+  VCHECK(a->out_mode == 0 || a->out_mode == 1, VACNIC_BAD_DTYPE, "gemv_ln: out_mode 0 (bf16) or 1 (f32)");
+  VCHECK(a->ldo >= a->N, VACNIC_BAD_SHAPE, "gemv_ln: ldo < N");
+  GemvLnP p;
+  p.x = (const bf16_t*)a->x; p.res = (const bf16_t*)a->residual; p.gamma = a->gamma; p.beta = a->beta; p.ln_out = (bf16_t*)a->ln_out;
+  p.w = (const bf16_t*)a->w; p.bias = a->bias; p.out = a->out;
+  p.M = (int)a->M; p.N = (int)a->N; p.K = (int)a->K; p.ldw = (int)a->ldw; p.ldo = (int)a->ldo; p.act = a->act; p.out_mode = a->out_mode;
+  p.eps = a->eps;
+  constexpr int CW = 4;
+  const dim3 grid((unsigned)((a->N + CW - 1) / CW));
+  if (a->K <= 512) hipLaunchKernelGGL((gemv_ln_kernel<8, CW, 1>), grid, dim3(64), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((gemv_ln_kernel<8, CW, 2>), grid, dim3(64), 0, (hipStream_t)stream, p);
+  VLAUNCH_CHECK();
+  return VACNIC_OK;
+}
 
 // ---- host-side tile selection --------------------------------------------------------------------------------
 // Cost model in "MFMA work units" (bm*bn*k elements): a launch needs ceil(tiles / resident slots) rounds; a round

@@ -86,10 +86,13 @@ class CachedDecoder:
         for j in range(nb):
             K.copy3d(enc_h, self.enc_b[j::nb], B, S, d)
         self.enc_mask.copy_(mask_u8.repeat_interleave(nb, dim=0))
-        M = self.rows * S
+        # one caption (B == 1): all beams attend to the SAME source, so the cross-attention K/V are projected once for the single
+        # row and every beam reads them through a batch stride of 0 (5x fewer bytes per token, L2-resident after the first beam)
+        self.shared_kv = B == 1
+        src, M = (enc_h, S) if self.shared_kv else (self.enc_b, self.rows * S)
         for li, layer in enumerate(self.dec.layers):
             a = layer.encoder_attn
-            K.gemm(self.enc_b.view(M, d), a.s_kv.w16, M, 2 * d, d, bias=a.s_kv.bias, out=self.cross[li].view(M, 2 * d))
+            K.gemm(src.reshape(M, d), a.s_kv.w16, M, 2 * d, d, bias=a.s_kv.bias, out=self.cross[li].view(self.rows * S, 2 * d)[:M])
 
     def cache_at(self, t):
         return self.cache[t & 1] if self.reorders else self.cache[0]
@@ -101,27 +104,58 @@ class CachedDecoder:
         h, _, _ = K.embed_ln_fwd(ids_t, dec.embed_tokens.weight.w16, dec.embed_positions.weight.w16, ln.weight.data, ln.bias.data,
                                  embed_scale=dec.embed_scale, pos_offset=2 + t)
         cache = self.cache_at(t)
+        # R <= 8 rows (one caption, <= 8 beams): every post-LN (residual add + LayerNorm) rides as a prologue on the projection
+        # that consumes it (vacnic_gemv_ln_bf16) — 36 fewer launches per token, bit-identical values.  `pend` = the block output
+        # and residual whose LayerNorm has not been applied yet.
+        fuse = R <= 8 and d <= 1024 and d % 8 == 0
+        pend = None
+
+        def ln_then(lnm, w, N, bias, out=None, ldo=None, act=None, out_mode=0):
+            o_, res_ = pend
+            hn = torch.empty((R, d), device=o_.device, dtype=BF16)
+            y = K.gemv_ln(o_.view(R, d), res_.view(R, d), lnm.weight.data, lnm.bias.data, w, R, N, d, bias=bias, out=out, ln_out=hn,
+                          ldw=w.stride(0), ldo=ldo, act=act, out_mode=out_mode, eps=lnm.eps)
+            return y, hn
+
         for li, layer in enumerate(dec.layers):
             a = layer.self_attn
             row = cache[li][:, t]                                                               # [R, 2d] view, row stride (Tmax+1)*2d
-            K.gemm(h.view(R, d), a.s_kvq.w16, R, 3 * d, d, bias=a.s_kvq.bias, out=row, ldo=row.stride(0))   # k|v|q in place
+            if pend is None:
+                K.gemm(h.view(R, d), a.s_kvq.w16, R, 3 * d, d, bias=a.s_kvq.bias, out=row, ldo=row.stride(0))   # k|v|q in place
+            else:
+                _, h = ln_then(pend_ln, a.s_kvq.w16, 3 * d, a.s_kvq.bias, out=row, ldo=row.stride(0))
             q = cache[li][:, t + 1:t + 2, :d]
             ctx, _ = K.attn_fwd(q, cache[li][:, :t + 1, :d], cache[li][:, :t + 1, d:], R, H, 1, t + 1, need_lse=False)
             o = K.gemm(ctx.view(R, d), a.s_out.w16, R, d, d, bias=a.s_out.bias)
-            h, _, _ = K.add_ln_fwd(o.view(R, 1, d), h, layer.self_attn_layer_norm.weight.data, layer.self_attn_layer_norm.bias.data,
-                                   need_stats=False)
             c = layer.encoder_attn
-            q = K.gemm(h.view(R, d), c.s_q.w16, R, d, d, bias=c.s_q.bias).view(R, 1, d)
-            kv = self.cross[li]
+            if fuse:
+                pend = (o, h)
+                q, h = ln_then(layer.self_attn_layer_norm, c.s_q.w16, d, c.s_q.bias)
+                q = q.view(R, 1, d)
+            else:
+                h, _, _ = K.add_ln_fwd(o.view(R, 1, d), h, layer.self_attn_layer_norm.weight.data, layer.self_attn_layer_norm.bias.data,
+                                       need_stats=False)
+                q = K.gemm(h.view(R, d), c.s_q.w16, R, d, d, bias=c.s_q.bias).view(R, 1, d)
+            kv = self.cross[li][:1].expand(R, -1, -1) if self.shared_kv else self.cross[li]
             ctx, _ = K.attn_fwd(q, kv[..., :d], kv[..., d:], R, H, 1, kv.shape[1], key_mask=self.enc_mask, need_lse=False)
             o = K.gemm(ctx.view(R, d), c.s_out.w16, R, d, d, bias=c.s_out.bias)
-            h, _, _ = K.add_ln_fwd(o.view(R, 1, d), h, layer.encoder_attn_layer_norm.weight.data, layer.encoder_attn_layer_norm.bias.data,
-                                   need_stats=False)
-            f = K.gemm(h.view(R, d), layer.s_fc1.w16, R, layer.s_fc1.N, d, bias=layer.s_fc1.bias, act="gelu")
+            if fuse:
+                pend = (o, h)
+                f, h = ln_then(layer.encoder_attn_layer_norm, layer.s_fc1.w16, layer.s_fc1.N, layer.s_fc1.bias, act="gelu")
+            else:
+                h, _, _ = K.add_ln_fwd(o.view(R, 1, d), h, layer.encoder_attn_layer_norm.weight.data, layer.encoder_attn_layer_norm.bias.data,
+                                       need_stats=False)
+                f = K.gemm(h.view(R, d), layer.s_fc1.w16, R, layer.s_fc1.N, d, bias=layer.s_fc1.bias, act="gelu")
             o = K.gemm(f, layer.s_fc2.w16, R, d, layer.s_fc2.K, bias=layer.s_fc2.bias)
-            h, _, _ = K.add_ln_fwd(o.view(R, 1, d), h, layer.final_layer_norm.weight.data, layer.final_layer_norm.bias.data, need_stats=False)
+            if fuse:
+                pend, pend_ln = (o, h), layer.final_layer_norm
+            else:
+                h, _, _ = K.add_ln_fwd(o.view(R, 1, d), h, layer.final_layer_norm.weight.data, layer.final_layer_norm.bias.data, need_stats=False)
         logits = torch.empty((R, m.V_pad), device=h.device, dtype=torch.float32)
-        K.gemm(h.view(R, d), m.emb16_pad, R, m.V, d, bias=m.final_logits_bias.view(-1), out=logits, ldo=m.V_pad, out_mode=1)
+        if fuse and pend is not None:
+            ln_then(pend_ln, m.emb16_pad, m.V, m.final_logits_bias.view(-1), out=logits, ldo=m.V_pad, out_mode=1)
+        else:
+            K.gemm(h.view(R, d), m.emb16_pad, R, m.V, d, bias=m.final_logits_bias.view(-1), out=logits, ldo=m.V_pad, out_mode=1)
         return logits
 
     def reorder(self, beam_idx, t):

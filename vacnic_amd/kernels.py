@@ -109,6 +109,16 @@ def gemm(x, w, M, N, K, *, bias=None, out=None, ldx=None, ldw=None, ldo=None, x_
     return out
 
 
+def gemv_ln(x, residual, gamma, beta, w, M, N, Kd, *, bias=None, out=None, ln_out=None, ldw=None, ldo=None, act=None, out_mode=0, eps=1e-5):
+    """out = epi(LayerNorm(x + residual) . w^T + bias) for M <= 8 rows; ln_out (optional) receives the normalised rows."""
+    if out is None:
+        out = torch.empty((M, N), device=x.device, dtype=BF16 if out_mode == 0 else torch.float32)
+    call_struct("vacnic_gemv_ln_bf16", stream=_stream(), x=_p(x), residual=_p(residual), gamma=_p(gamma), beta=_p(beta), ln_out=_p(ln_out),
+                w=_p(w), bias=_p(bias), out=_p(out), M=M, N=N, K=Kd, ldw=ldw if ldw is not None else Kd, ldo=ldo if ldo is not None else N,
+                act=ACT[act], out_mode=out_mode, eps=eps)
+    return out
+
+
 def wgrad_split(M_red, n_tiles):
     """split-K factor for a weight gradient whose reduction runs over M_red rows: aim at >= 512 workgroups."""
     s = 1
