@@ -342,6 +342,7 @@ def main():
     timer = GemmTimer()
     from vacnic_amd import _lib as _vlib
     calls0 = _vlib.CALLS
+    cpu0 = time.thread_time()
     t0 = time.perf_counter()
     out4 = None
     for i in range(a.steps):
@@ -361,6 +362,7 @@ def main():
     timer.remove()
     host_dt = time.perf_counter() - t0           # host-side enqueue time of the K steps (GPU may still be running)
     calls_per_step = (_vlib.CALLS - calls0) / a.steps
+    host_cpu = (time.thread_time() - cpu0) / a.steps     # CPU time of the launching thread (enqueue wall time also contains back-pressure waits)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -414,7 +416,7 @@ def main():
                "launch_mode": ("hipGraph replay (K-1 steps) + 1 eager instrumented step" if graphed is not None else
                                "eager multi-stream" + (", frozen towers as hipGraph replays" if towers is not None else "")),
                "host_enqueue_ms_per_step": round(host_dt / a.steps * 1e3, 2),
-               "c_abi_calls_per_step": round(calls_per_step, 1),
+               "c_abi_calls_per_step": round(calls_per_step, 1), "host_cpu_ms_per_step": round(host_cpu * 1e3, 2),
                "per_rank_ms_per_step": per_rank_ms,
                "world_size_reported": dist.get_world_size() if world > 1 else 1,
                "dist_backend": (backend if world > 1 else None), "grad_transport": (a.grad_transport if world > 1 else None),
