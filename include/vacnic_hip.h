@@ -333,6 +333,42 @@ typedef struct {
 int vacnic_beam_init(const vacnic_beam_state* st, int32_t start_token, void* stream);
 int vacnic_beam_step(const vacnic_beam_state* st, const float* top_val, const int32_t* top_idx, int32_t K2, int32_t cur_len,
                      void* stream);
+/*
+ * Persistent single-token decoder step: every BartDecoderLayer of one position (MFULL:793-890 with
+ * past_key_value, eval mode: self-attention over the KV cache, cross-attention over the encoder K/V projected once, FFN, the
+ * three post-LayerNorms) in ONE launch — one workgroup per CU, grid barriers between the 8 phases of a layer, the next
+ * projection's weights prefetched into registers behind each barrier.  R <= 8 rows (beams x batch), d_model <= 1024 with
+ * 64-wide heads, ffn_dim <= 4096.  Values are bit-identical to the kernel-per-op chain vacnic_gemv_ln_bf16 /
+ * vacnic_gemm_bf16 (skinny) / vacnic_attn_fwd (Tq = 1).
+ *   layers   DEVICE array [L] of vacnic_decoder_layer: bf16 weights row-major [N][K] contiguous (w_kvq = k|v|q stacked, [3d][d]),
+ *            fp32 biases and LayerNorm parameters; cross_kv bf16 [rows][S][2d] (k|v per source position) with cross_bs
+ *            elements between rows (0: all rows share one source — the beams of one caption).
+ *   cache    bf16 [L][R][Tmax + 1][2d]: k|v of position t are written at [l][r][t][0:2d], q is parked at [l][r][t + 1][0:d].
+ *   h0       bf16 [R][d]: embedding LayerNorm output of the new token (vacnic_embed_ln_fwd).
+ *   hbuf/obuf/ctx/qbuf ([R][d]) and fbuf ([R][F]): scratch.  On return the last layer's un-normalised block output is obuf and
+ *            its residual is hbuf[L & 1]; final_layer_norm of the last layer is left to the consumer (vacnic_gemv_ln_bf16 with
+ *            the LM head).
+ *   sync     vacnic_decoder_step_sync_bytes() bytes, zeroed ONCE by the caller; word [sync_bytes / 4 - 32] is an error flag the
+ *            kernel raises (and leaves) if a grid barrier times out — check it when the results are read back.
+ */
+typedef struct {
+  const void *w_kvq, *w_so, *w_cq, *w_co, *w_fc1, *w_fc2;
+  const float *b_kvq, *b_so, *b_cq, *b_co, *b_fc1, *b_fc2;
+  const float *ln_self_g, *ln_self_b, *ln_cross_g, *ln_cross_b, *ln_final_g, *ln_final_b;
+  const void* cross_kv;
+  int64_t cross_bs;
+} vacnic_decoder_layer;
+typedef struct {
+  const vacnic_decoder_layer* layers;
+  void* cache; const void* h0;
+  void* hbuf[2]; void* obuf; void* ctx; void* qbuf; void* fbuf;
+  const uint8_t* enc_mask;        /* uint8 [R][S], 0 = masked source position; may be NULL */
+  uint32_t* sync;
+  int64_t L, R, d, H, F, S, t, Tmax;
+  float eps, scale;
+} vacnic_decoder_step_args;
+int64_t vacnic_decoder_step_sync_bytes(void);
+int vacnic_decoder_step(const vacnic_decoder_step_args* a, void* stream);
 /* dst[r] = src[idx[r]] for rows of row_bytes (multiple of 16): KV-cache beam reorder (_reorder_cache, MFULL:2066-2074). */
 int vacnic_gather_rows(const void* src, void* dst, const int64_t* idx, int64_t rows, int64_t row_bytes, void* stream);
 

@@ -749,3 +749,52 @@ def test_whole_step_hipgraph_replays_like_eager():
         np.testing.assert_allclose(runs[1], runs[0], rtol=5e-3, atol=1e-4)
     finally:
         streams.enable(False)
+
+
+@pytest.mark.parametrize("case", ["bart_base_shape", "bart_large_shape"])
+def test_decoder_step_kernel_matches_per_op_path(case, monkeypatch):
+    """the persistent decoder-step kernel (all layers of a position in ONE launch, grid barriers between the
+    phases) must give bit-identical logits and KV-cache rows to the kernel-per-op chain it replaces (gemv_ln / skinny GEMM /
+    single-query attention), including beam reorders between positions, a masked source and both attention key-split modes
+    (S < 256: one wave per (row, head); S >= 256: four)."""
+    from vacnic_amd import generate as Gn, synthetic
+    from vacnic_amd.config import ClipVisionConfig
+    from vacnic_amd.training import build_models
+    if case == "bart_base_shape":
+        cfg, R, nb, S, Tmax = small_cfg(encoder_layers=1, decoder_layers=2), 6, 3, 24, 12
+    else:
+        cfg = small_cfg(d_model=1024, encoder_layers=1, decoder_layers=3, encoder_attention_heads=16, decoder_attention_heads=16,
+                        encoder_ffn_dim=4096, decoder_ffn_dim=4096, dim_common=1024, clip_width=1024)
+        R, nb, S, Tmax = 5, 5, 300, 10
+    vcfg = ClipVisionConfig(width=128, layers=1, patch_size=16, image_size=32, output_dim=64)
+    sd = synthetic.make_state_dict(synthetic.mmbart_param_shapes(cfg), seed=1)
+    sd["model.shared.weight"] = sd["model.shared.weight"] * synthetic.GEN_SHARPEN
+    model, _, _ = build_models(cfg, vcfg, init="synthetic",
+                               state_dicts=(sd, synthetic.make_state_dict(synthetic.guide_bart_param_shapes(cfg), seed=2),
+                                            synthetic.make_state_dict(synthetic.clip_visual_param_shapes(vcfg), seed=4, std=0.05)))
+    model.eval()
+    B = R // nb
+    g = torch.Generator().manual_seed(5)
+    enc_h = (torch.randn(B, S, cfg.d_model, generator=g) * 0.7).bfloat16().cuda()
+    mask = torch.ones(B, S, dtype=torch.uint8)
+    mask[:, S - 5:] = 0                                        # padded source tail
+    mask = mask.cuda()
+    fast = Gn.CachedDecoder(model, R, S, Tmax, reorders=True)
+    assert fast.step_kernel, "the step kernel must be the default for <= 8 rows"
+    monkeypatch.setenv("VACNIC_DECODE_PER_OP", "1")
+    ref = Gn.CachedDecoder(model, R, S, Tmax, reorders=True)
+    assert not ref.step_kernel
+    with torch.no_grad():
+        fast.begin(enc_h, mask, nb); ref.begin(enc_h, mask, nb)
+        for t in range(Tmax - 1):
+            ids = torch.randint(3, cfg.vocab_size, (R, 1), generator=g).cuda()
+            if t > 0:
+                src = torch.randint(0, nb, (R,), generator=g)
+                src = (src + (torch.arange(R) // nb) * nb).cuda()       # beams stay inside their batch item
+                fast.reorder(src, t); ref.reorder(src, t)
+            la = fast.step(ids, t)
+            lb = ref.step(ids, t)
+            torch.cuda.synchronize()
+            assert torch.equal(fast.cache_at(t)[:, :, :t + 1], ref.cache_at(t)[:, :, :t + 1]), (case, t, "KV cache rows differ")
+            assert torch.equal(la[:, :model.V], lb[:, :model.V]), (case, t, (la[:, :model.V] - lb[:, :model.V]).abs().max().item())
+    fast.check_step_kernel()

@@ -115,6 +115,17 @@ BeamState = _struct("vacnic_beam_state", [
     ("B", i64), ("nb", i64), ("Lmax", i64), ("V", i64), ("eos", i64), ("pad", i64), ("no_repeat_ngram_size", i64), ("early_stopping", i64),
     ("length_penalty", f32)])
 
+DecoderLayer = _struct("vacnic_decoder_layer", [
+    ("w_kvq", vp), ("w_so", vp), ("w_cq", vp), ("w_co", vp), ("w_fc1", vp), ("w_fc2", vp),
+    ("b_kvq", vp), ("b_so", vp), ("b_cq", vp), ("b_co", vp), ("b_fc1", vp), ("b_fc2", vp),
+    ("ln_self_g", vp), ("ln_self_b", vp), ("ln_cross_g", vp), ("ln_cross_b", vp), ("ln_final_g", vp), ("ln_final_b", vp),
+    ("cross_kv", vp), ("cross_bs", i64)])
+
+DecoderStepArgs = _struct("vacnic_decoder_step_args", [
+    ("layers", vp), ("cache", vp), ("h0", vp), ("hbuf0", vp), ("hbuf1", vp), ("obuf", vp), ("ctx", vp), ("qbuf", vp), ("fbuf", vp),
+    ("enc_mask", vp), ("sync", vp),
+    ("L", i64), ("R", i64), ("d", i64), ("H", i64), ("F", i64), ("S", i64), ("t", i64), ("Tmax", i64), ("eps", f32), ("scale", f32)])
+
 AdamwArgs = _struct("vacnic_adamw_args", [
     ("p", vp), ("g", vp), ("m", vp), ("v", vp), ("p_bf16", vp), ("hyper", vp),
     ("n", i64), ("beta1", f32), ("beta2", f32), ("eps", f32), ("weight_decay", f32), ("grad_scale", f32),
@@ -130,6 +141,7 @@ _STRUCT_FNS = {
     "vacnic_colam_fwd": ColamFwdArgs, "vacnic_colam_bwd": ColamBwdArgs,
     "vacnic_secla_fwd": SeclaFwdArgs, "vacnic_secla_bwd": SeclaBwdArgs,
     "vacnic_name_embed_mean": NameEmbedArgs, "vacnic_adamw": AdamwArgs, "vacnic_lmhead_ce_fwd": LmheadCeArgs,
+    "vacnic_decoder_step": DecoderStepArgs,
 }
 _PLAIN_FNS = {
     "vacnic_combine_losses": [vp, vp, vp, vp, f32, f32, vp, vp],
@@ -157,7 +169,7 @@ _PLAIN_FNS = {
     "vacnic_beam_init": [C.POINTER(BeamState), i32, vp],
     "vacnic_beam_step": [C.POINTER(BeamState), vp, vp, i32, i32, vp],
 }
-EXPORTED = sorted(list(_STRUCT_FNS) + list(_PLAIN_FNS) + ["vacnic_last_error_string", "vacnic_version"])
+EXPORTED = sorted(list(_STRUCT_FNS) + list(_PLAIN_FNS) + ["vacnic_last_error_string", "vacnic_version", "vacnic_decoder_step_sync_bytes"])
 
 for _name, _st in _STRUCT_FNS.items():
     _fn = getattr(lib, _name)          # AttributeError here = stale .so: fail loudly
@@ -171,6 +183,8 @@ lib.vacnic_last_error_string.restype = C.c_char_p
 lib.vacnic_last_error_string.argtypes = []
 lib.vacnic_version.restype = C.c_int
 lib.vacnic_version.argtypes = []
+lib.vacnic_decoder_step_sync_bytes.restype = C.c_int64
+lib.vacnic_decoder_step_sync_bytes.argtypes = []
 
 _VALUE_ERRORS = (1, 2, 3)   # bad shape / dtype / alignment -> ValueError like the reference's shape checks
 

@@ -1,0 +1,665 @@
+// decstep.hip — the single-token decoder step of caption generation as ONE persistent kernel.
+//
+// What it replaces: BartDecoderLayer.forward with past_key_value (MFULL:793-890: self-attention over the KV cache, cross-attention
+// over the encoder K/V projected once, FFN, three post-LayerNorms; eval mode) for all decoder layers of one position — 8 dependent
+// launches per layer in the kernel-per-op path (gemv_ln / gemm_skinny / attn_decode), each 6-12 us for 2-8 MB of weights.
+//
+// Design.  G = one workgroup per CU (256 threads) walks the 8 phases of every layer; phases are separated by a grid barrier
+// (two-level arrive over 16 counters + 16 release flags on their own cache lines: 1.6 us at G = 256, tools/gridbar_probe.hip)
+// instead of a kernel boundary (~5 us + cold caches), and the weights of the NEXT projection are pulled into registers between
+// the arrive and the wait of a barrier — they do not depend on the activations, so the HBM round trip of a phase is hidden
+// behind the barrier it follows.
+//   P1  x = LN(o + h)      -> k|v|q = x Wkvq^T + b        (written in place into the KV cache row of position t)
+//   P2  self-attention over cache[0..t]                     one (row, head) pair per workgroup
+//   P3  o = ctx Wo^T + b
+//   P4  x = LN(o + h) -> h -> q = x Wq^T + b
+//   P5  cross-attention over the encoder K/V (key mask)     one (row, head) pair per workgroup, 4 waves split the keys
+//   P6  o = ctx Wo^T + b
+//   P7  x = LN(o + h) -> h -> f = gelu(x W1^T + b)
+//   P8  o = f W2^T + b                                      (the last layer's (o, h) pair is normalised by the LM-head kernel)
+// Activations that cross a phase (k|v|q, ctx, o, h, q, f: <= 8 rows) live in HBM and are exchanged with sc1 buffer loads /
+// stores (agent-coherent: write-through, miss-always in the XCD's L2; a store is complete when vmcnt says so) — release /
+// acquire fences (buffer_wbl2 / buffer_inv) cost 20-35 us per phase on this part, sc1 traffic costs nothing measurable.
+// Weights, the cross-attention K/V and LayerNorm parameters are read-only for the launch and use ordinary cached loads.
+//
+// Arithmetic: the same per-lane accumulation order, wave-reduction tree and bf16 rounding points as vacnic_gemv_ln_bf16,
+// gemm_skinny_kernel and attn_decode_kernel, so the logits of a position are bit-identical to the kernel-per-op path
+// (tests/test_model_gpu.py::test_decoder_step_kernel_matches_per_op_path).
+//
+// Safety: a barrier wait that exceeds ~2 s (100 MHz wall clock) sets the error word and every workgroup leaves; the last
+// workgroup out clears the barrier state, so a launch always drains and the next one starts clean.
+#include "common.h"
+
+namespace {
+
+constexpr int NTHR = 256, NWAVE = 4, MR = 8;
+constexpr int NGRP = 16, NFLAG = 16;
+constexpr int COH = 16;                       // aux bits of the buffer intrinsics: sc1
+// barrier state (uint32 words, one 128-byte line each): grp[16] | top | flag[16] | exit | err
+constexpr int BAR_TOP = 32 * NGRP, BAR_FLAG = 32 * (NGRP + 1), BAR_EXIT = 32 * (NGRP + 1 + NFLAG), BAR_ERR = BAR_EXIT + 32;
+#define AGENT __HIP_MEMORY_SCOPE_AGENT
+
+struct DecP {
+  const vacnic_decoder_layer* layers;
+  bf16_t* cache; const bf16_t* h0;
+  bf16_t *hb0, *hb1, *o, *ctx, *q, *f;
+  const uint8_t* enc_mask;
+  unsigned* bar;
+  int L, R, d, H, F, S, t, Tstride;           // Tstride = (Tmax + 1) * 2d elements between two rows of one layer's cache
+  unsigned cache_bytes, xs_bytes;
+  float eps, scale;
+};
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t mkrs(const void* p, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, bytes, 0x00020000); }
+__device__ __forceinline__ u32x4 cld(rsrc_t rs, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, COH); }
+__device__ __forceinline__ void cst(u32x4 v, rsrc_t rs, unsigned off) { __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, COH); }
+__device__ __forceinline__ void cst16(float v, rsrc_t rs, unsigned off) { __builtin_amdgcn_raw_buffer_store_b16((short)f2bf(v), rs, off, 0, COH); }
+
+__device__ __forceinline__ void unpack8(u32x4 r, float v[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(r[i] << 16); v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u); }
+}
+
+// ---- grid barrier ------------------------------------------------------------------------------------------------
+struct Bar { unsigned* base; int G; unsigned ph; bool last; };
+
+// every thread has waited for its own stores (s_waitcnt vmcnt(0)) before this
+__device__ __forceinline__ void bar_arrive(Bar& b) {
+  __syncthreads();
+  b.ph += 1;
+  if (threadIdx.x == 0) {
+    const int g = blockIdx.x % NGRP;
+    const unsigned gsize = (unsigned)((b.G - g + NGRP - 1) / NGRP);
+    const unsigned ngrp = (unsigned)(b.G < NGRP ? b.G : NGRP);
+    bool last = __hip_atomic_fetch_add(b.base + 32 * g, 1u, __ATOMIC_RELAXED, AGENT) + 1 == b.ph * gsize;
+    if (last) last = __hip_atomic_fetch_add(b.base + BAR_TOP, 1u, __ATOMIC_RELAXED, AGENT) + 1 == b.ph * ngrp;
+    if (last) {
+#pragma unroll
+      for (int f = 0; f < NFLAG; ++f) __hip_atomic_store(b.base + BAR_FLAG + 32 * f, b.ph, __ATOMIC_RELAXED, AGENT);
+    }
+    b.last = last;
+  }
+}
+__device__ __forceinline__ bool bar_wait(Bar& b, int* s_bad) {
+  if (threadIdx.x == 0) {
+    if (!b.last) {
+      unsigned* fl = b.base + BAR_FLAG + 32 * (blockIdx.x % NFLAG);
+      const long long t0 = wall_clock64();
+      unsigned polls = 0;
+      while (__hip_atomic_load(fl, __ATOMIC_RELAXED, AGENT) < b.ph) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++polls & 1023u) == 0 &&
+            (wall_clock64() - t0 > 200000000ll || __hip_atomic_load(b.base + BAR_ERR, __ATOMIC_RELAXED, AGENT) != 0)) {
+          __hip_atomic_store(b.base + BAR_ERR, 1u, __ATOMIC_RELAXED, AGENT);
+          *s_bad = 1;
+          break;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  return *s_bad == 0;
+}
+
+// ---- weight prefetch --------------------------------------------------------------------------------------------------
+// The next projection's weights are ISSUED between the arrive and the wait of a barrier and must stay in flight across it.
+// They go HBM -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`: no destination VGPRs, so nothing the register allocator could
+// move or spill while the data is still on its way, and an intrinsic with side effects is not sunk behind the wait the way
+// plain C++ loads were).  Every wave owns private 1-KiB slots (one per 64-lane x 16-byte piece: lane-linear, conflict-free
+// to read back) and only ever reads its own, so `s_waitcnt vmcnt(0)` by that wave is all the synchronisation needed.
+// Columns >= N and chunks >= K / 8 point outside the descriptor and are zero-filled.
+constexpr unsigned OOB = 0x7ffffff0u;
+constexpr int WBIG = 8 * 1024, WSMALL = 2 * 1024;       // bytes per wave: 4 columns x 2 chunks / 1 column x 2 chunks
+__device__ __forceinline__ void wdma(rsrc_t wrs, char* slot, unsigned voff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, LDS_PTR(slot), 16, (int)voff, 0, 0, 0);
+}
+__device__ __forceinline__ void w_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ u32x4 w_get(const char* wl, int slot, int lane) { return *(const u32x4*)(wl + slot * 1024 + lane * 16); }
+
+// C columns n0 .. n0+C-1 of W [N][K] for one wave, K <= 1024: chunks lane, lane + 64 -> slots c * 2 + i
+template <int C>
+__device__ __forceinline__ void w_issue(char* wl, rsrc_t wrs, int N, int K, int n0, int lane) {
+  const int nchunk = K >> 3;
+#pragma unroll
+  for (int c = 0; c < C; ++c)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ch = lane + 64 * i, n = n0 + c;
+      wdma(wrs, wl + (c * 2 + i) * 1024, (ch < nchunk && n < N) ? (unsigned)(n * K + ch * 8) * 2u : OOB);
+    }
+}
+// 4 columns per workgroup, K <= 4096 split over the 4 waves: chunks lane + 64 * wave + 256 * i
+__device__ __forceinline__ void w2_issue(char* wl, rsrc_t wrs, int N, int K, int n0, int wave, int lane) {
+  const int nchunk = K >> 3;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ch = lane + 64 * wave + 256 * i, n = n0 + c;
+      wdma(wrs, wl + (c * 2 + i) * 1024, (ch < nchunk && n < N) ? (unsigned)(n * K + ch * 8) * 2u : OOB);
+    }
+}
+
+struct OutD { rsrc_t rs; unsigned base, rstride; };     // byte offset of (row 0, column 0) and row stride in bytes
+
+// reduce-scatter butterflies over the 64 lanes (xor offsets 32, 16, 8, 4, 2, 1 — the tree of gemm_skinny_kernel)
+#define VAC_BFLY(OFF, HALF)                                                      \
+  {                                                                              \
+    const bool up = (lane & OFF) != 0;                                           \
+    _Pragma("unroll") for (int i = 0; i < HALF; ++i) {                           \
+      const float send = up ? acc[i] : acc[HALF + i];                            \
+      const float keep = up ? acc[HALF + i] : acc[i];                            \
+      acc[i] = keep + __shfl_xor(send, OFF, 64);                                 \
+    }                                                                            \
+  }
+__device__ __forceinline__ float bfly32(float (&acc)[32], int lane, int& idx, bool& owner) {
+  VAC_BFLY(32, 16) VAC_BFLY(16, 8) VAC_BFLY(8, 4) VAC_BFLY(4, 2) VAC_BFLY(2, 1)
+  const float v = acc[0] + __shfl_xor(acc[0], 1, 64);
+  idx = (((lane >> 5) & 1) << 4) | (((lane >> 4) & 1) << 3) | (((lane >> 3) & 1) << 2) | (((lane >> 2) & 1) << 1) | ((lane >> 1) & 1);
+  owner = (lane & 1) == 0;
+  return v;
+}
+__device__ __forceinline__ float bfly8(float (&acc)[8], int lane, int& idx, bool& owner) {
+  VAC_BFLY(32, 4) VAC_BFLY(16, 2) VAC_BFLY(8, 1)
+  float v = acc[0];
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 1, 64);
+  idx = (((lane >> 5) & 1) << 2) | (((lane >> 4) & 1) << 1) | ((lane >> 3) & 1);
+  owner = (lane & 7) == 0;
+  return v;
+}
+#undef VAC_BFLY
+
+// one wave: C output columns n0 .. n0+C-1 for all R rows; x (bf16, LDS) [R][K]
+template <int C>
+__device__ __forceinline__ void gemv_tile(const char* wl, const bf16_t* xs, int R, int N, int K, int n0, const float* bias, int act,
+                                          const OutD& o, int lane) {
+  constexpr int NV = MR * C;
+  float acc[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) acc[i] = 0.f;
+  const int nchunk = K >> 3;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nchunk) {
+      float wv[C][8];
+#pragma unroll
+      for (int c = 0; c < C; ++c) unpack8(w_get(wl, c * 2 + i, lane), wv[c]);
+#pragma unroll
+      for (int m = 0; m < MR; ++m) {
+        if (m < R) {
+          float xv[8];
+          unpack8(*(const u32x4*)(xs + (size_t)m * K + ch * 8), xv);
+#pragma unroll
+          for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[m * C + c] += xv[j] * wv[c][j];
+        }
+      }
+    }
+  }
+  int idx; bool owner; float v;
+  if constexpr (C == 4) v = bfly32(acc, lane, idx, owner);
+  else v = bfly8(acc, lane, idx, owner);
+  if (owner) {
+    const int m = idx / C, c = idx % C, n = n0 + c;
+    if (m < R && n < N) {
+      if (bias) v += bias[n];
+      v = act_fwd(act, v);
+      cst16(v, o.rs, o.base + (unsigned)m * o.rstride + (unsigned)n * 2u);
+    }
+  }
+}
+
+template <int C>
+__device__ __forceinline__ void gemv_phase(char* wl, rsrc_t wrs, const float* bias, int N, int K, int act, const OutD& o,
+                                           const bf16_t* xs, int R, int G, int wg, int wave, int lane) {
+  const int ntile = (N + NWAVE * C - 1) / (NWAVE * C);
+  for (int T = wg; T < ntile; T += G) {
+    const int n0 = (T * NWAVE + wave) * C;
+    if (T != wg) w_issue<C>(wl, wrs, N, K, n0, lane);          // tiles beyond the prefetched one (N > 4 C G)
+    w_wait();
+    gemv_tile<C>(wl, xs, R, N, K, n0, bias, act, o, lane);
+  }
+}
+
+// long reduction (fc2): a workgroup owns 4 columns, its 4 waves split K and meet in LDS (gemm_skinny_kernel<8, 4, 4>)
+__device__ __forceinline__ void gemv2_phase(char* wl, rsrc_t wrs, const float* bias, int N, int K, const OutD& o, const bf16_t* xs,
+                                            int R, int G, int wg, int wave, int lane, float (*part)[32]) {
+  const int ntile = (N + 3) / 4;
+  const int nchunk = K >> 3;
+  for (int T = wg; T < ntile; T += G) {
+    const int n0 = T * 4;
+    if (T != wg) w2_issue(wl, wrs, N, K, n0, wave, lane);
+    w_wait();
+    float acc[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ch = lane + 64 * wave + 256 * i;
+      if (ch < nchunk) {
+        float wv[4][8];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) unpack8(w_get(wl, c * 2 + i, lane), wv[c]);
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+          if (m < R) {
+            float xv[8];
+            unpack8(*(const u32x4*)(xs + (size_t)m * K + ch * 8), xv);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+              for (int j = 0; j < 8; ++j) acc[m * 4 + c] += xv[j] * wv[c][j];
+          }
+        }
+      }
+    }
+    int idx; bool owner;
+    float v = bfly32(acc, lane, idx, owner);
+    if (owner) part[wave][idx] = v;
+    __syncthreads();
+    if (wave == 0 && owner) {
+      v = 0.f;
+#pragma unroll
+      for (int w = 0; w < NWAVE; ++w) v += part[w][idx];
+      const int m = idx / 4, c = idx % 4, n = n0 + c;
+      if (m < R && n < N) {
+        if (bias) v += bias[n];
+        cst16(v, o.rs, o.base + (unsigned)m * o.rstride + (unsigned)n * 2u);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---- x -> LDS ------------------------------------------------------------------------------------------------------
+// rows of a phase-crossing activation (bf16 [R][K], contiguous) into LDS
+__device__ __forceinline__ void stage_plain(rsrc_t src, bf16_t* xs, int R, int K, int tid) {
+  const int n = R * (K >> 3);
+  for (int c0 = tid; c0 < n; c0 += 4 * NTHR) {
+    u32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = c0 + u * NTHR;
+      v[u] = c < n ? cld(src, (unsigned)c * 16u) : (u32x4){0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = c0 + u * NTHR;
+      if (c < n) *(u32x4*)(xs + (size_t)c * 8) = v[u];
+    }
+  }
+}
+
+// x = LayerNorm(o + h) (add_ln_fwd_kernel's arithmetic: one wave per row, chunks lane / lane + 64, fp32 statistics), rounded
+// to bf16 into LDS; workgroup 0 also writes the rows to hnew — the next block's residual.
+__device__ __forceinline__ void stage_ln(rsrc_t osrc, rsrc_t hsrc, const float* gamma, const float* beta, rsrc_t hnew, bool write_h,
+                                         bf16_t* xs, int R, int K, float eps, int wave, int lane) {
+  const int nchunk = K >> 3;
+  u32x4 xraw[2][2], rraw[2][2];
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = wave + NWAVE * rr, ch = lane + 64 * i;
+      xraw[rr][i] = (u32x4){0, 0, 0, 0}; rraw[rr][i] = (u32x4){0, 0, 0, 0};
+      if (m < R && ch < nchunk) {
+        xraw[rr][i] = cld(osrc, (unsigned)(m * K + ch * 8) * 2u);
+        rraw[rr][i] = cld(hsrc, (unsigned)(m * K + ch * 8) * 2u);
+      }
+    }
+  float gam[2][8], bet[2][8];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ch = lane + 64 * i;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { gam[i][j] = 0.f; bet[i][j] = 0.f; }
+    if (ch < nchunk) {
+      const f32x4 g0 = *(const f32x4*)(gamma + ch * 8), g1 = *(const f32x4*)(gamma + ch * 8 + 4);
+      const f32x4 b0 = *(const f32x4*)(beta + ch * 8), b1 = *(const f32x4*)(beta + ch * 8 + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { gam[i][j] = g0[j]; gam[i][4 + j] = g1[j]; bet[i][j] = b0[j]; bet[i][4 + j] = b1[j]; }
+    }
+  }
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) {
+    const int m = wave + NWAVE * rr;
+    if (m >= R) continue;
+    float h[2][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (lane + 64 * i < nchunk) {
+        float xv[8], rv[8];
+        unpack8(xraw[rr][i], xv);
+        unpack8(rraw[rr][i], rv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { xv[j] += rv[j]; h[i][j] = xv[j]; s += xv[j]; }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) h[i][j] = 0.f;
+      }
+    }
+    const float mean = wave_sum(s) / K;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (lane + 64 * i < nchunk) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float dd = h[i][j] - mean; q += dd * dd; }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / K + eps);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nchunk) {
+        float y[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = (h[i][j] - mean) * rstd * gam[i][j] + bet[i][j];
+        const u32x4 packed = (u32x4){pack2bf(y[0], y[1]), pack2bf(y[2], y[3]), pack2bf(y[4], y[5]), pack2bf(y[6], y[7])};
+        *(u32x4*)(xs + (size_t)m * K + ch * 8) = packed;
+        if (write_h) cst(packed, hnew, (unsigned)(m * K + ch * 8) * 2u);
+      }
+    }
+  }
+}
+
+// ---- single-query attention of one (row, head) pair (attn_decode_kernel's arithmetic) -------------------------------------
+// q: 64 bf16 at qoff of qrs (coherent).  Keys / values: rows j = 0..Tk-1 at koff + j * ldb / voff + j * ldb of kvrs (AUX = COH
+// for the self-attention cache, whose newest row was written in this launch; 0 for the static cross-attention K/V).
+// nw = 4 waves split the keys when Tk >= 256 (as the per-op path picks attn_decode_kernel<4>), else wave 0 alone.
+template <int AUX>
+__device__ __forceinline__ void attn_pair(rsrc_t qrs, unsigned qoff, rsrc_t kvrs, unsigned koff, unsigned voff, unsigned ldb, int Tk,
+                                          const uint8_t* km, float scale, rsrc_t ors, unsigned ooff, float* probs, int wave, int lane) {
+  const int nw = Tk >= 256 ? NWAVE : 1;
+  const int per = (Tk + nw - 1) / nw;
+  const int k_lo = wave * per, k_hi = wave < nw ? min(Tk, k_lo + per) : k_lo;
+  float m = -INFINITY, l = 0.f;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  const int kg = lane >> 3, dc = lane & 7;
+  if (wave < nw) {
+    float qf[64];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const u32x4 r = cld(qrs, qoff + c * 16);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { qf[c * 8 + 2 * i] = __uint_as_float(r[i] << 16); qf[c * 8 + 2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u); }
+    }
+    for (int key0 = k_lo + lane; key0 < k_hi; key0 += 256) {
+      u32x4 kr[4][8];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int key = key0 + 64 * u;
+        const unsigned ro = koff + (unsigned)(key < k_hi ? key : key0) * ldb;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) kr[u][c] = __builtin_amdgcn_raw_buffer_load_b128(kvrs, ro + c * 16, 0, AUX);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int key = key0 + 64 * u;
+        if (key < k_hi) {
+          float dot = 0.f;
+#pragma unroll
+          for (int c = 0; c < 8; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              dot += qf[c * 8 + 2 * i] * __uint_as_float(kr[u][c][i] << 16);
+              dot += qf[c * 8 + 2 * i + 1] * __uint_as_float(kr[u][c][i] & 0xffff0000u);
+            }
+          float sc = dot * scale;
+          if (km && km[key] == 0) sc += -3.4028234663852886e38f;
+          probs[key] = sc;
+          m = fmaxf(m, sc);
+        }
+      }
+    }
+    m = wave_max(m);
+    for (int key = k_lo + lane; key < k_hi; key += 64) {
+      const float e = __expf(probs[key] - m);
+      probs[key] = e;
+      l += e;
+    }
+    l = wave_sum(l);
+  }
+  __syncthreads();
+  if (wave < nw) {
+    for (int key0 = k_lo + kg; key0 < k_hi; key0 += 64) {
+      u32x4 vr[8]; float pk[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int key = key0 + 8 * u;
+        const bool ok = key < k_hi;
+        vr[u] = __builtin_amdgcn_raw_buffer_load_b128(kvrs, voff + (unsigned)(ok ? key : key0) * ldb + dc * 16, 0, AUX);
+        pk[u] = ok ? probs[key] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc[2 * i] += pk[u] * __uint_as_float(vr[u][i] << 16);
+          acc[2 * i + 1] += pk[u] * __uint_as_float(vr[u][i] & 0xffff0000u);
+        }
+    }
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], o, 64);
+  }
+  if (nw > 1) {
+    float* pacc = probs + Tk;                          // [4][64]
+    float* pm = pacc + NWAVE * 64;                     // [4]
+    float* pl = pm + NWAVE;                            // [4]
+    if (kg == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pacc[wave * 64 + dc * 8 + j] = acc[j];
+    }
+    if (lane == 0) { pm[wave] = m; pl[wave] = l; }
+    __syncthreads();
+    if (wave == 0) {
+      float gm = pm[0];
+#pragma unroll
+      for (int w = 1; w < NWAVE; ++w) gm = fmaxf(gm, pm[w]);
+      float gl = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+      for (int w = 0; w < NWAVE; ++w) {
+        const float sc = pl[w] > 0.f ? __expf(pm[w] - gm) : 0.f;
+        gl += pl[w] * sc;
+        if (kg == 0) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] += pacc[w * 64 + dc * 8 + j] * sc;
+        }
+      }
+      l = gl;
+    }
+  }
+  if (wave == 0 && kg == 0) {
+    const float inv = 1.f / l;
+    cst((u32x4){pack2bf(acc[0] * inv, acc[1] * inv), pack2bf(acc[2] * inv, acc[3] * inv), pack2bf(acc[4] * inv, acc[5] * inv),
+                pack2bf(acc[6] * inv, acc[7] * inv)}, ors, ooff + dc * 16);
+  }
+}
+
+__device__ __forceinline__ int wave_of(int tid) { return __builtin_amdgcn_readfirstlane(tid >> 6); }
+
+#define END_PHASE(PREFETCH)                                     \
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              \
+  bar_arrive(bar);                                              \
+  { PREFETCH; }                                                 \
+  if (!bar_wait(bar, &s_bad)) return;
+
+__global__ __launch_bounds__(NTHR) void decoder_step_kernel(DecP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* xs = (bf16_t*)smem;                                   // [R][max(d, F)] bf16
+  char* wbig = smem + p.xs_bytes + wave_of(threadIdx.x) * WBIG;                         // this wave's prefetch slots
+  char* wsml = smem + p.xs_bytes + NWAVE * WBIG + wave_of(threadIdx.x) * WSMALL;
+  float* probs = (float*)(smem + p.xs_bytes + NWAVE * (WBIG + WSMALL));   // [max(S, t + 1)] + 4 * 64 + 8
+  __shared__ float part[NWAVE][32];
+  __shared__ int s_bad;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int G = gridDim.x, wg = blockIdx.x;
+  const int R = p.R, d = p.d, F = p.F, H = p.H;
+  if (tid == 0) s_bad = 0;
+  Bar bar = {p.bar, G, 0u, false};
+
+  const unsigned act_b = (unsigned)(R * d * 2), f_b = (unsigned)(R * F * 2);
+  const rsrc_t rs_cache = mkrs(p.cache, p.cache_bytes);
+  const rsrc_t rs_h0 = mkrs(p.h0, act_b), rs_hb0 = mkrs(p.hb0, act_b), rs_hb1 = mkrs(p.hb1, act_b);
+  const rsrc_t rs_o = mkrs(p.o, act_b), rs_ctx = mkrs(p.ctx, act_b), rs_q = mkrs(p.q, act_b), rs_f = mkrs(p.f, f_b);
+  const OutD out_o = {rs_o, 0u, (unsigned)(d * 2)}, out_q = {rs_q, 0u, (unsigned)(d * 2)}, out_f = {rs_f, 0u, (unsigned)(F * 2)};
+  rsrc_t hcur = rs_h0;
+  int nln = 0;                                                  // LayerNorm k writes hb[k & 1]
+  const unsigned row_b = (unsigned)p.Tstride * 2u;              // bytes between two rows of one layer's cache
+  const int Tk_self = p.t + 1;
+
+  const unsigned wb_dd = (unsigned)(d * d * 2), wb_fd = (unsigned)(F * d * 2);
+  w_issue<4>(wbig, mkrs(p.layers[0].w_kvq, 3 * wb_dd), 3 * d, d, (wg * NWAVE + wave) * 4, lane);
+
+  for (int li = 0; li < p.L; ++li) {
+    const vacnic_decoder_layer& ly = p.layers[li];
+    const unsigned lay_b = (unsigned)li * (unsigned)R * row_b;
+    // ---- P1: k|v|q of position t, in place in the cache (k|v at row t, q parked in the first d columns of row t + 1)
+    if (li == 0) {
+      stage_plain(rs_h0, xs, R, d, tid);
+    } else {
+      const vacnic_decoder_layer& pv = p.layers[li - 1];
+      const rsrc_t hn = (nln & 1) ? rs_hb1 : rs_hb0;
+      stage_ln(rs_o, hcur, pv.ln_final_g, pv.ln_final_b, hn, wg == 0, xs, R, d, p.eps, wave, lane);
+      hcur = hn; ++nln;
+    }
+    __syncthreads();
+    {
+      const OutD out_c = {rs_cache, lay_b + (unsigned)p.t * (unsigned)(2 * d) * 2u, row_b};
+      gemv_phase<4>(wbig, mkrs(ly.w_kvq, 3 * wb_dd), ly.b_kvq, 3 * d, d, VACNIC_ACT_NONE, out_c, xs, R, G, wg, wave, lane);
+    }
+    END_PHASE(w_issue<1>(wsml, mkrs(ly.w_so, wb_dd), d, d, wg * NWAVE + wave, lane))
+    // ---- P2: self-attention over cache rows 0..t
+    for (int pr = wg; pr < R * H; pr += G) {
+      const int r = pr / H, h = pr - r * H;
+      const unsigned rb = lay_b + (unsigned)r * row_b + (unsigned)h * 128u;
+      attn_pair<COH>(rs_cache, rb + (unsigned)(p.t + 1) * (unsigned)(2 * d) * 2u, rs_cache, rb, rb + (unsigned)d * 2u, (unsigned)(2 * d) * 2u,
+                     Tk_self, nullptr, p.scale, rs_ctx, (unsigned)(r * d + h * 64) * 2u, probs, wave, lane);
+      __syncthreads();
+    }
+    END_PHASE()
+    // ---- P3: self-attention output projection
+    stage_plain(rs_ctx, xs, R, d, tid);
+    __syncthreads();
+    gemv_phase<1>(wsml, mkrs(ly.w_so, wb_dd), ly.b_so, d, d, VACNIC_ACT_NONE, out_o, xs, R, G, wg, wave, lane);
+    END_PHASE(w_issue<1>(wsml, mkrs(ly.w_cq, wb_dd), d, d, wg * NWAVE + wave, lane))
+    // ---- P4: post-LN of the self-attention block, cross-attention query
+    {
+      const rsrc_t hn = (nln & 1) ? rs_hb1 : rs_hb0;
+      stage_ln(rs_o, hcur, ly.ln_self_g, ly.ln_self_b, hn, wg == 0, xs, R, d, p.eps, wave, lane);
+      hcur = hn; ++nln;
+    }
+    __syncthreads();
+    gemv_phase<1>(wsml, mkrs(ly.w_cq, wb_dd), ly.b_cq, d, d, VACNIC_ACT_NONE, out_q, xs, R, G, wg, wave, lane);
+    END_PHASE(w_issue<1>(wsml, mkrs(ly.w_co, wb_dd), d, d, wg * NWAVE + wave, lane))
+    // ---- P5: cross-attention over the encoder K/V
+    {
+      const unsigned kv_rows = ly.cross_bs == 0 ? 1u : (unsigned)R;
+      const rsrc_t rs_kv = mkrs(ly.cross_kv, kv_rows * (unsigned)p.S * (unsigned)(2 * d) * 2u);
+      for (int pr = wg; pr < R * H; pr += G) {
+        const int r = pr / H, h = pr - r * H;
+        const unsigned kb = (unsigned)r * (unsigned)ly.cross_bs * 2u + (unsigned)h * 128u;
+        attn_pair<0>(rs_q, (unsigned)(r * d + h * 64) * 2u, rs_kv, kb, kb + (unsigned)d * 2u, (unsigned)(2 * d) * 2u, p.S,
+                     p.enc_mask ? p.enc_mask + (size_t)r * p.S : nullptr, p.scale, rs_ctx, (unsigned)(r * d + h * 64) * 2u, probs, wave, lane);
+        __syncthreads();
+      }
+    }
+    END_PHASE()
+    // ---- P6: cross-attention output projection
+    stage_plain(rs_ctx, xs, R, d, tid);
+    __syncthreads();
+    gemv_phase<1>(wsml, mkrs(ly.w_co, wb_dd), ly.b_co, d, d, VACNIC_ACT_NONE, out_o, xs, R, G, wg, wave, lane);
+    END_PHASE(w_issue<4>(wbig, mkrs(ly.w_fc1, wb_fd), F, d, (wg * NWAVE + wave) * 4, lane))
+    // ---- P7: post-LN of the cross-attention block, fc1 + GELU
+    {
+      const rsrc_t hn = (nln & 1) ? rs_hb1 : rs_hb0;
+      stage_ln(rs_o, hcur, ly.ln_cross_g, ly.ln_cross_b, hn, wg == 0, xs, R, d, p.eps, wave, lane);
+      hcur = hn; ++nln;
+    }
+    __syncthreads();
+    gemv_phase<4>(wbig, mkrs(ly.w_fc1, wb_fd), ly.b_fc1, F, d, VACNIC_ACT_GELU, out_f, xs, R, G, wg, wave, lane);
+    END_PHASE(w2_issue(wbig, mkrs(ly.w_fc2, wb_fd), d, F, wg * 4, wave, lane))
+    // ---- P8: fc2
+    stage_plain(rs_f, xs, R, F, tid);
+    __syncthreads();
+    gemv2_phase(wbig, mkrs(ly.w_fc2, wb_fd), ly.b_fc2, d, F, out_o, xs, R, G, wg, wave, lane, part);
+    if (li + 1 < p.L) {
+      END_PHASE(w_issue<4>(wbig, mkrs(p.layers[li + 1].w_kvq, 3 * wb_dd), 3 * d, d, (wg * NWAVE + wave) * 4, lane))
+    }
+  }
+  // exit: the last workgroup out clears the barrier state (stream order makes it visible to the next launch)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    if (__hip_atomic_fetch_add(p.bar + BAR_EXIT, 1u, __ATOMIC_RELAXED, AGENT) == (unsigned)G - 1) {
+      for (int i = 0; i < NGRP; ++i) __hip_atomic_store(p.bar + 32 * i, 0u, __ATOMIC_RELAXED, AGENT);
+      __hip_atomic_store(p.bar + BAR_TOP, 0u, __ATOMIC_RELAXED, AGENT);
+      for (int f = 0; f < NFLAG; ++f) __hip_atomic_store(p.bar + BAR_FLAG + 32 * f, 0u, __ATOMIC_RELAXED, AGENT);
+      __hip_atomic_store(p.bar + BAR_EXIT, 0u, __ATOMIC_RELAXED, AGENT);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t vacnic_decoder_step_sync_bytes(void) { return (int64_t)(BAR_ERR + 32) * 4; }
+
+extern "C" int vacnic_decoder_step(const vacnic_decoder_step_args* a, void* stream) {
+  VCHECK(a && a->layers && a->cache && a->h0 && a->hbuf[0] && a->hbuf[1] && a->obuf && a->ctx && a->qbuf && a->fbuf && a->sync,
+         VACNIC_BAD_SHAPE, "decoder_step: null operand");
+  VCHECK(a->L >= 1 && a->R >= 1 && a->R <= MR, VACNIC_UNSUPPORTED, "decoder_step: 1 <= R <= 8 rows (beams x batch), L >= 1");
+  VCHECK(a->d >= 64 && a->d <= 1024 && (a->d & 7) == 0 && a->H * 64 == a->d, VACNIC_UNSUPPORTED,
+         "decoder_step: d_model <= 1024, multiple of 8, heads of 64");
+  VCHECK(a->F >= 8 && a->F <= 4096 && (a->F & 7) == 0, VACNIC_UNSUPPORTED, "decoder_step: ffn_dim <= 4096, multiple of 8");
+  VCHECK(a->S >= 1 && a->S <= 8192 && a->t >= 0 && a->t < a->Tmax && a->Tmax <= 8191, VACNIC_BAD_SHAPE, "decoder_step: 0 <= t < Tmax, 1 <= S <= 8192");
+  const int64_t cache_bytes = a->L * a->R * (a->Tmax + 1) * 2 * a->d * 2;
+  VCHECK(cache_bytes < ((int64_t)1 << 31) && a->R * a->S * 2 * a->d * 2 < ((int64_t)1 << 31), VACNIC_UNSUPPORTED, "decoder_step: cache beyond 2 GiB");
+  VCHECK(aligned16(a->cache) && aligned16(a->h0) && aligned16(a->hbuf[0]) && aligned16(a->hbuf[1]) && aligned16(a->obuf) && aligned16(a->ctx) &&
+         aligned16(a->qbuf) && aligned16(a->fbuf), VACNIC_MISALIGNED, "decoder_step: 16-byte aligned buffers");
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) {
+      vacnic_set_error("decoder_step: cannot query the CU count");
+      return VACNIC_HIP_ERROR;
+    }
+    n_cu = v;
+  }
+  DecP p;
+  p.layers = a->layers; p.cache = (bf16_t*)a->cache; p.h0 = (const bf16_t*)a->h0;
+  p.hb0 = (bf16_t*)a->hbuf[0]; p.hb1 = (bf16_t*)a->hbuf[1]; p.o = (bf16_t*)a->obuf; p.ctx = (bf16_t*)a->ctx; p.q = (bf16_t*)a->qbuf;
+  p.f = (bf16_t*)a->fbuf; p.enc_mask = a->enc_mask; p.bar = a->sync;
+  p.L = (int)a->L; p.R = (int)a->R; p.d = (int)a->d; p.H = (int)a->H; p.F = (int)a->F; p.S = (int)a->S; p.t = (int)a->t;
+  p.Tstride = (int)((a->Tmax + 1) * 2 * a->d);
+  p.cache_bytes = (unsigned)cache_bytes;
+  const int64_t kmax = a->d > a->F ? a->d : a->F;
+  p.xs_bytes = (unsigned)(a->R * kmax * 2);
+  p.eps = a->eps; p.scale = a->scale;
+  const int64_t tkmax = a->S > a->t + 1 ? a->S : a->t + 1;
+  const size_t lds = (size_t)p.xs_bytes + (size_t)NWAVE * (WBIG + WSMALL) + (size_t)(tkmax + NWAVE * 64 + 8) * 4;
+  VCHECK(lds <= 150 * 1024, VACNIC_UNSUPPORTED, "decoder_step: LDS budget");
+  static size_t lds_set = 0;
+  if (lds > 65536 - 1024 && lds > lds_set) {
+    if (hipFuncSetAttribute((const void*)decoder_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(150 * 1024)) != hipSuccess) {
+      vacnic_set_error("decoder_step: cannot raise the dynamic LDS limit");
+      return VACNIC_HIP_ERROR;
+    }
+    lds_set = 150 * 1024;
+  }
+  const int G = n_cu < 256 ? n_cu : 256;
+  hipLaunchKernelGGL(decoder_step_kernel, dim3(G), dim3(NTHR), lds, (hipStream_t)stream, p);
+  VLAUNCH_CHECK();
+  return VACNIC_OK;
+}

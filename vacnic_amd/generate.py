@@ -15,9 +15,11 @@ What runs where
 The cache is preallocated ([layers, B*beams, max_length, 2d] bf16, k|v interleaved per row) instead of the reference's
 per-step torch.cat (MFULL:489-492).
 """
+import os
+
 import torch
 
-from . import kernels as K
+from . import _lib, kernels as K
 
 BF16 = torch.bfloat16
 
@@ -78,6 +80,18 @@ class CachedDecoder:
         self.enc_mask = torch.empty((rows, S), device=dev, dtype=torch.uint8)
         self.cross = [torch.empty((rows, S, 2 * d), device=dev, dtype=BF16) for _ in range(self.L)]
         self.lidx = (torch.arange(self.L, device=dev)[:, None] * rows).contiguous()
+        # persistent decoder-step kernel (vacnic_decoder_step): all layers of a position in one launch.  VACNIC_DECODE_PER_OP=1
+        # keeps the kernel-per-op chain (the reference the step kernel is tested against).
+        F = dec.layers[0].fc1.weight.shape[0]
+        self.F = F
+        self.step_kernel = (os.environ.get("VACNIC_DECODE_PER_OP", "0") != "1" and rows <= 8 and d <= 1024 and d % 8 == 0 and F <= 4096
+                            and F % 8 == 0 and self.H * 64 == d and max_length <= 8191)
+        self.step_table = None
+        if self.step_kernel:
+            self.sync = torch.zeros(int(_lib.lib.vacnic_decoder_step_sync_bytes()) // 4, device=dev, dtype=torch.int32)
+            self.hbuf = [torch.zeros((rows, d), device=dev, dtype=BF16) for _ in range(2)]
+            self.obuf, self.ctxb, self.qbuf = (torch.zeros((rows, d), device=dev, dtype=BF16) for _ in range(3))
+            self.fbuf = torch.zeros((rows, F), device=dev, dtype=BF16)
 
     def begin(self, enc_h, mask_u8, nb):
         """expand the encoder states to beams (HF _expand_inputs_for_generation: row b*nb + j <- batch b) and compute the
@@ -96,6 +110,48 @@ class CachedDecoder:
 
     def cache_at(self, t):
         return self.cache[t & 1] if self.reorders else self.cache[0]
+
+    def _layer_table(self):
+        """device array of vacnic_decoder_layer (weights / biases / LayerNorm parameters / cross K|V of every layer)."""
+        if self.step_table is None or self.step_table[1] != self.shared_kv:
+            d, S = self.d, self.S
+            arr = (_lib.DecoderLayer * self.L)()
+            for li, layer in enumerate(self.dec.layers):
+                a, c = layer.self_attn, layer.encoder_attn
+                mats = {"w_kvq": (a.s_kvq.w16, 3 * d, d), "w_so": (a.s_out.w16, d, d), "w_cq": (c.s_q.w16, d, d), "w_co": (c.s_out.w16, d, d),
+                        "w_fc1": (layer.s_fc1.w16, self.F, d), "w_fc2": (layer.s_fc2.w16, d, self.F)}
+                for name, (w, n, k) in mats.items():
+                    if tuple(w.shape) != (n, k) or not w.is_contiguous():
+                        raise ValueError(f"decoder_step: {name} of layer {li} must be a contiguous [{n}, {k}] matrix, got {tuple(w.shape)}")
+                    setattr(arr[li], name, w.data_ptr())
+                for name, b in (("b_kvq", a.s_kvq.bias), ("b_so", a.s_out.bias), ("b_cq", c.s_q.bias), ("b_co", c.s_out.bias),
+                                ("b_fc1", layer.s_fc1.bias), ("b_fc2", layer.s_fc2.bias)):
+                    setattr(arr[li], name, b.data_ptr() if b is not None else None)
+                for name, ln in (("ln_self", layer.self_attn_layer_norm), ("ln_cross", layer.encoder_attn_layer_norm),
+                                 ("ln_final", layer.final_layer_norm)):
+                    setattr(arr[li], name + "_g", ln.weight.data.data_ptr())
+                    setattr(arr[li], name + "_b", ln.bias.data.data_ptr())
+                arr[li].cross_kv = self.cross[li].data_ptr()
+                arr[li].cross_bs = 0 if self.shared_kv else S * 2 * d
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            self.step_table = (host.to(self.cache[0].device), self.shared_kv)
+        return self.step_table[0]
+
+    def _step_all_layers(self, h, t):
+        """every decoder layer of position t in one launch; returns the last layer's (block output, residual) pair."""
+        lay = self.dec.layers[0]
+        _lib.call_struct("vacnic_decoder_step", stream=K._stream(), layers=self._layer_table().data_ptr(), cache=self.cache_at(t).data_ptr(),
+                         h0=h.data_ptr(), hbuf0=self.hbuf[0].data_ptr(), hbuf1=self.hbuf[1].data_ptr(), obuf=self.obuf.data_ptr(),
+                         ctx=self.ctxb.data_ptr(), qbuf=self.qbuf.data_ptr(), fbuf=self.fbuf.data_ptr(), enc_mask=self.enc_mask.data_ptr(),
+                         sync=self.sync.data_ptr(), L=self.L, R=self.rows, d=self.d, H=self.H, F=self.F, S=self.S, t=t, Tmax=self.Tmax,
+                         eps=lay.final_layer_norm.eps, scale=0.125)
+        return self.obuf, self.hbuf[self.L & 1]
+
+    def check_step_kernel(self):
+        """after the results were read back: did a grid barrier of the step kernel time out?"""
+        if self.step_kernel and int(self.sync[-32].item()) != 0:
+            self.sync.zero_()
+            raise RuntimeError("vacnic_decoder_step: a grid barrier timed out (workgroups not co-resident?); results are invalid")
 
     def step(self, ids_t, t):
         """ids_t int64 [rows, 1] (token at position t) -> fp32 logits [rows, V_pad]."""
@@ -117,7 +173,10 @@ class CachedDecoder:
                           ldw=w.stride(0), ldo=ldo, act=act, out_mode=out_mode, eps=lnm.eps)
             return y, hn
 
-        for li, layer in enumerate(dec.layers):
+        if self.step_kernel:
+            pend = self._step_all_layers(h.view(R, d), t)
+            pend_ln = dec.layers[-1].final_layer_norm
+        for li, layer in enumerate(dec.layers if not self.step_kernel else ()):
             a = layer.self_attn
             row = cache[li][:, t]                                                               # [R, 2d] view, row stride (Tmax+1)*2d
             if pend is None:
@@ -241,6 +300,7 @@ class DecodeSession:
                 break
         cur_len = steps + 1                                  # tokens in every live history
         seqs = self.seq[steps & 1].cpu()
+        self.dec.check_step_kernel()
         return (cur_len, seqs, self.scores_s.cpu(), self.done_d.cpu(), self.hyp_cnt.cpu(), self.hyp_score.cpu(), self.hyp_len.cpu(),
                 self.hyp_seq.cpu())
 
@@ -289,7 +349,9 @@ class DecodeSession:
             tv, ti = self.outs[t]
         else:
             tv, ti = self.body(t)
-        return tv.cpu(), ti.cpu()
+        tv, ti = tv.cpu(), ti.cpu()
+        self.dec.check_step_kernel()
+        return tv, ti
 
 
 @torch.no_grad()
