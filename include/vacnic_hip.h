@@ -338,8 +338,8 @@ int vacnic_beam_step(const vacnic_beam_state* st, const float* top_val, const in
  * past_key_value, eval mode: self-attention over the KV cache, cross-attention over the encoder K/V projected once, FFN, the
  * three post-LayerNorms) in ONE launch — one workgroup per CU, grid barriers between the 8 phases of a layer, the next
  * projection's weights prefetched into registers behind each barrier.  R <= 8 rows (beams x batch), d_model <= 1024 with
- * 64-wide heads, ffn_dim <= 4096.  Values are bit-identical to the kernel-per-op chain vacnic_gemv_ln_bf16 /
- * vacnic_gemm_bf16 (skinny) / vacnic_attn_fwd (Tq = 1).
+ * 64-wide heads, ffn_dim <= 4096.  Same accumulation order and rounding points as the kernel-per-op chain vacnic_gemv_ln_bf16 /
+ * vacnic_gemm_bf16 (skinny) / vacnic_attn_fwd (Tq = 1); results agree to the last bit up to fma-contraction choices of the compiler.
  *   layers   DEVICE array [L] of vacnic_decoder_layer: bf16 weights row-major [N][K] contiguous (w_kvq = k|v|q stacked, [3d][d]),
  *            fp32 biases and LayerNorm parameters; cross_kv bf16 [rows][S][2d] (k|v per source position) with cross_bs
  *            elements between rows (0: all rows share one source — the beams of one caption).
@@ -366,6 +366,9 @@ typedef struct {
   uint32_t* sync;
   int64_t L, R, d, H, F, S, t, Tmax;
   float eps, scale;
+  uint64_t* trace; int64_t trace_wg;   /* profiling aid, normally NULL: 100 MHz time stamps of workgroup trace_wg, uint64 [8 L][8]
+                                          ([phase][0] phase start, [1] inputs staged, [3] results stored, [4] stores acknowledged,
+                                          [5] arrived at the barrier + next weights issued) */
 } vacnic_decoder_step_args;
 int64_t vacnic_decoder_step_sync_bytes(void);
 int vacnic_decoder_step(const vacnic_decoder_step_args* a, void* stream);

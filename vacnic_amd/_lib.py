@@ -124,7 +124,8 @@ DecoderLayer = _struct("vacnic_decoder_layer", [
 DecoderStepArgs = _struct("vacnic_decoder_step_args", [
     ("layers", vp), ("cache", vp), ("h0", vp), ("hbuf0", vp), ("hbuf1", vp), ("obuf", vp), ("ctx", vp), ("qbuf", vp), ("fbuf", vp),
     ("enc_mask", vp), ("sync", vp),
-    ("L", i64), ("R", i64), ("d", i64), ("H", i64), ("F", i64), ("S", i64), ("t", i64), ("Tmax", i64), ("eps", f32), ("scale", f32)])
+    ("L", i64), ("R", i64), ("d", i64), ("H", i64), ("F", i64), ("S", i64), ("t", i64), ("Tmax", i64), ("eps", f32), ("scale", f32),
+    ("trace", vp), ("trace_wg", i64)])
 
 AdamwArgs = _struct("vacnic_adamw_args", [
     ("p", vp), ("g", vp), ("m", vp), ("v", vp), ("p_bf16", vp), ("hyper", vp),

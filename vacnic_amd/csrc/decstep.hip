@@ -23,8 +23,9 @@
 // Weights, the cross-attention K/V and LayerNorm parameters are read-only for the launch and use ordinary cached loads.
 //
 // Arithmetic: the same per-lane accumulation order, wave-reduction tree and bf16 rounding points as vacnic_gemv_ln_bf16,
-// gemm_skinny_kernel and attn_decode_kernel, so the logits of a position are bit-identical to the kernel-per-op path
-// (tests/test_model_gpu.py::test_decoder_step_kernel_matches_per_op_path).
+// gemm_skinny_kernel and attn_decode_kernel: the logits of a position match the kernel-per-op path bit for bit except where the
+// two compilations contract an fma differently (one bf16 ulp on a rare activation; -ffp-contract=fast leaves that to the
+// optimiser) — tests/test_model_gpu.py::test_decoder_step_kernel_matches_per_op_path.
 //
 // Safety: a barrier wait that exceeds ~2 s (100 MHz wall clock) sets the error word and every workgroup leaves; the last
 // workgroup out clears the barrier state, so a launch always drains and the next one starts clean.
@@ -48,6 +49,7 @@ struct DecP {
   int L, R, d, H, F, S, t, Tstride;           // Tstride = (Tmax + 1) * 2d elements between two rows of one layer's cache
   unsigned cache_bytes, xs_bytes;
   float eps, scale;
+  unsigned long long* trace; int trace_wg;    // profiling aid: 100 MHz time stamps of one workgroup, [phase][8]
 };
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
@@ -98,6 +100,7 @@ __device__ __forceinline__ bool bar_wait(Bar& b, int* s_bad) {
       }
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's prefetch DMA has landed -> visible to the whole workgroup below
   __syncthreads();
   return *s_bad == 0;
 }
@@ -141,6 +144,22 @@ __device__ __forceinline__ void w2_issue(char* wl, rsrc_t wrs, int N, int K, int
     }
 }
 
+// LayerNorm parameters (fp32 gamma | beta, K <= 1024 each) into the workgroup's shared slot: wave w moves piece w of both
+__device__ __forceinline__ void ln_issue(float* lnp, const float* gamma, const float* beta, int K, int wave, int lane) {
+  const rsrc_t rg = mkrs(gamma, (unsigned)K * 4u), rb = mkrs(beta, (unsigned)K * 4u);
+  const int f0 = wave * 256 + lane * 4;
+  const unsigned voff = f0 < K ? (unsigned)f0 * 4u : OOB;
+  wdma(rg, (char*)lnp + wave * 1024, voff);
+  wdma(rb, (char*)(lnp + 1024) + wave * 1024, voff);
+}
+// the bias values of this workgroup's first column tile (<= 16 columns) into the shared slot, by wave 0 (one 4-byte DMA piece)
+__device__ __forceinline__ void bias_issue(float* biasl, const float* bias, int N, int n_first, int ncols, int wave, int lane) {
+  if (wave == 0) {
+    const rsrc_t rb = mkrs(bias, bias ? (unsigned)N * 4u : 0u);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(biasl), 4, (int)((lane < ncols && n_first + lane < N) ? (unsigned)(n_first + lane) * 4u : OOB), 0, 0, 0);
+  }
+}
+
 struct OutD { rsrc_t rs; unsigned base, rstride; };     // byte offset of (row 0, column 0) and row stride in bytes
 
 // reduce-scatter butterflies over the 64 lanes (xor offsets 32, 16, 8, 4, 2, 1 — the tree of gemm_skinny_kernel)
@@ -174,8 +193,8 @@ __device__ __forceinline__ float bfly8(float (&acc)[8], int lane, int& idx, bool
 
 // one wave: C output columns n0 .. n0+C-1 for all R rows; x (bf16, LDS) [R][K]
 template <int C>
-__device__ __forceinline__ void gemv_tile(const char* wl, const bf16_t* xs, int R, int N, int K, int n0, const float* bias, int act,
-                                          const OutD& o, int lane) {
+__device__ __forceinline__ void gemv_tile(const char* wl, const bf16_t* xs, int R, int N, int K, int n0, const float* bias, const float* biasl,
+                                          int act, const OutD& o, int lane) {
   constexpr int NV = MR * C;
   float acc[NV];
 #pragma unroll
@@ -207,7 +226,8 @@ __device__ __forceinline__ void gemv_tile(const char* wl, const bf16_t* xs, int 
   if (owner) {
     const int m = idx / C, c = idx % C, n = n0 + c;
     if (m < R && n < N) {
-      if (bias) v += bias[n];
+      if (biasl) v += biasl[c];
+      else if (bias) v += bias[n];
       v = act_fwd(act, v);
       cst16(v, o.rs, o.base + (unsigned)m * o.rstride + (unsigned)n * 2u);
     }
@@ -215,26 +235,24 @@ __device__ __forceinline__ void gemv_tile(const char* wl, const bf16_t* xs, int 
 }
 
 template <int C>
-__device__ __forceinline__ void gemv_phase(char* wl, rsrc_t wrs, const float* bias, int N, int K, int act, const OutD& o,
+__device__ __forceinline__ void gemv_phase(char* wl, rsrc_t wrs, const float* bias, const float* biasl, int N, int K, int act, const OutD& o,
                                            const bf16_t* xs, int R, int G, int wg, int wave, int lane) {
   const int ntile = (N + NWAVE * C - 1) / (NWAVE * C);
   for (int T = wg; T < ntile; T += G) {
     const int n0 = (T * NWAVE + wave) * C;
-    if (T != wg) w_issue<C>(wl, wrs, N, K, n0, lane);          // tiles beyond the prefetched one (N > 4 C G)
-    w_wait();
-    gemv_tile<C>(wl, xs, R, N, K, n0, bias, act, o, lane);
+    if (T != wg) { w_issue<C>(wl, wrs, N, K, n0, lane); w_wait(); }         // tiles beyond the prefetched one (N > 4 C G)
+    gemv_tile<C>(wl, xs, R, N, K, n0, bias, T == wg ? biasl + wave * C : nullptr, act, o, lane);
   }
 }
 
 // long reduction (fc2): a workgroup owns 4 columns, its 4 waves split K and meet in LDS (gemm_skinny_kernel<8, 4, 4>)
-__device__ __forceinline__ void gemv2_phase(char* wl, rsrc_t wrs, const float* bias, int N, int K, const OutD& o, const bf16_t* xs,
+__device__ __forceinline__ void gemv2_phase(char* wl, rsrc_t wrs, const float* bias, const float* biasl, int N, int K, const OutD& o, const bf16_t* xs,
                                             int R, int G, int wg, int wave, int lane, float (*part)[32]) {
   const int ntile = (N + 3) / 4;
   const int nchunk = K >> 3;
   for (int T = wg; T < ntile; T += G) {
     const int n0 = T * 4;
-    if (T != wg) w2_issue(wl, wrs, N, K, n0, wave, lane);
-    w_wait();
+    if (T != wg) { w2_issue(wl, wrs, N, K, n0, wave, lane); w_wait(); }
     float acc[32];
 #pragma unroll
     for (int i = 0; i < 32; ++i) acc[i] = 0.f;
@@ -268,7 +286,8 @@ __device__ __forceinline__ void gemv2_phase(char* wl, rsrc_t wrs, const float* b
       for (int w = 0; w < NWAVE; ++w) v += part[w][idx];
       const int m = idx / 4, c = idx % 4, n = n0 + c;
       if (m < R && n < N) {
-        if (bias) v += bias[n];
+        if (T == wg) v += biasl[c];
+        else if (bias) v += bias[n];
         cst16(v, o.rs, o.base + (unsigned)m * o.rstride + (unsigned)n * 2u);
       }
     }
@@ -297,7 +316,7 @@ __device__ __forceinline__ void stage_plain(rsrc_t src, bf16_t* xs, int R, int K
 
 // x = LayerNorm(o + h) (add_ln_fwd_kernel's arithmetic: one wave per row, chunks lane / lane + 64, fp32 statistics), rounded
 // to bf16 into LDS; workgroup 0 also writes the rows to hnew — the next block's residual.
-__device__ __forceinline__ void stage_ln(rsrc_t osrc, rsrc_t hsrc, const float* gamma, const float* beta, rsrc_t hnew, bool write_h,
+__device__ __forceinline__ void stage_ln(rsrc_t osrc, rsrc_t hsrc, const float* lnp, rsrc_t hnew, bool write_h,
                                          bf16_t* xs, int R, int K, float eps, int wave, int lane) {
   const int nchunk = K >> 3;
   u32x4 xraw[2][2], rraw[2][2];
@@ -319,8 +338,8 @@ __device__ __forceinline__ void stage_ln(rsrc_t osrc, rsrc_t hsrc, const float* 
 #pragma unroll
     for (int j = 0; j < 8; ++j) { gam[i][j] = 0.f; bet[i][j] = 0.f; }
     if (ch < nchunk) {
-      const f32x4 g0 = *(const f32x4*)(gamma + ch * 8), g1 = *(const f32x4*)(gamma + ch * 8 + 4);
-      const f32x4 b0 = *(const f32x4*)(beta + ch * 8), b1 = *(const f32x4*)(beta + ch * 8 + 4);
+      const f32x4 g0 = *(const f32x4*)(lnp + ch * 8), g1 = *(const f32x4*)(lnp + ch * 8 + 4);
+      const f32x4 b0 = *(const f32x4*)(lnp + 1024 + ch * 8), b1 = *(const f32x4*)(lnp + 1024 + ch * 8 + 4);
 #pragma unroll
       for (int j = 0; j < 4; ++j) { gam[i][j] = g0[j]; gam[i][4 + j] = g1[j]; bet[i][j] = b0[j]; bet[i][4 + j] = b1[j]; }
     }
@@ -373,25 +392,87 @@ __device__ __forceinline__ void stage_ln(rsrc_t osrc, rsrc_t hsrc, const float* 
 // q: 64 bf16 at qoff of qrs (coherent).  Keys / values: rows j = 0..Tk-1 at koff + j * ldb / voff + j * ldb of kvrs (AUX = COH
 // for the self-attention cache, whose newest row was written in this launch; 0 for the static cross-attention K/V).
 // nw = 4 waves split the keys when Tk >= 256 (as the per-op path picks attn_decode_kernel<4>), else wave 0 alone.
-template <int AUX>
-__device__ __forceinline__ void attn_pair(rsrc_t qrs, unsigned qoff, rsrc_t kvrs, unsigned koff, unsigned voff, unsigned ldb, int Tk,
-                                          const uint8_t* km, float scale, rsrc_t ors, unsigned ooff, float* probs, int wave, int lane) {
-  const int nw = Tk >= 256 ? NWAVE : 1;
-  const int per = (Tk + nw - 1) / nw;
-  const int k_lo = wave * per, k_hi = wave < nw ? min(Tk, k_lo + per) : k_lo;
-  float m = -INFINITY, l = 0.f;
-  float acc[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+//
+// One wave's share [k_lo, k_hi) of the keys.  KU > 0: the share fits 64 * KU keys and EVERY load of the phase (q, the key rows,
+// the value rows) is issued before the first is consumed — the phase is a chain of dependent ~2 us round trips otherwise
+// (q -> keys -> values per 64 keys: 12 us for a 133-key share); the arithmetic and its order are unchanged.  KU == 0: any length.
+template <int AUX, int KU>
+__device__ __forceinline__ void attn_share(rsrc_t qrs, unsigned qoff, rsrc_t kvrs, unsigned koff, unsigned voff, unsigned ldb, int k_lo, int k_hi,
+                                           const uint8_t* km, float scale, float* probs, int lane, float& m, float& l, float (&acc)[8]) {
   const int kg = lane >> 3, dc = lane & 7;
-  if (wave < nw) {
+  u32x4 qr[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) qr[c] = cld(qrs, qoff + c * 16);
+  if constexpr (KU > 0) {
+    u32x4 kr[KU][8], vr[KU][8];
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      const int key = k_lo + lane + 64 * u;
+      const unsigned ro = koff + (unsigned)(key < k_hi ? key : k_lo) * ldb;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) kr[u][c] = __builtin_amdgcn_raw_buffer_load_b128(kvrs, ro + c * 16, 0, AUX);
+    }
+#pragma unroll
+    for (int it = 0; it < KU; ++it)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int key = k_lo + kg + 64 * it + 8 * u;
+        vr[it][u] = __builtin_amdgcn_raw_buffer_load_b128(kvrs, voff + (unsigned)(key < k_hi ? key : k_lo) * ldb + dc * 16, 0, AUX);
+      }
     float qf[64];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const u32x4 r = cld(qrs, qoff + c * 16);
+    for (int c = 0; c < 8; ++c)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { qf[c * 8 + 2 * i] = __uint_as_float(r[i] << 16); qf[c * 8 + 2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u); }
+      for (int i = 0; i < 4; ++i) { qf[c * 8 + 2 * i] = __uint_as_float(qr[c][i] << 16); qf[c * 8 + 2 * i + 1] = __uint_as_float(qr[c][i] & 0xffff0000u); }
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      const int key = k_lo + lane + 64 * u;
+      if (key < k_hi) {
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            dot += qf[c * 8 + 2 * i] * __uint_as_float(kr[u][c][i] << 16);
+            dot += qf[c * 8 + 2 * i + 1] * __uint_as_float(kr[u][c][i] & 0xffff0000u);
+          }
+        float sc = dot * scale;
+        if (km && km[key] == 0) sc += -3.4028234663852886e38f;
+        probs[key] = sc;
+        m = fmaxf(m, sc);
+      }
     }
+    m = wave_max(m);
+    for (int key = k_lo + lane; key < k_hi; key += 64) {
+      const float e = __expf(probs[key] - m);
+      probs[key] = e;
+      l += e;
+    }
+    l = wave_sum(l);
+#pragma unroll
+    for (int it = 0; it < KU; ++it) {
+      if (k_lo + kg + 64 * it < k_hi) {
+        float pk[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int key = k_lo + kg + 64 * it + 8 * u;
+          pk[u] = key < k_hi ? probs[key] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            acc[2 * i] += pk[u] * __uint_as_float(vr[it][u][i] << 16);
+            acc[2 * i + 1] += pk[u] * __uint_as_float(vr[it][u][i] & 0xffff0000u);
+          }
+      }
+    }
+  } else {
+    float qf[64];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { qf[c * 8 + 2 * i] = __uint_as_float(qr[c][i] << 16); qf[c * 8 + 2 * i + 1] = __uint_as_float(qr[c][i] & 0xffff0000u); }
     for (int key0 = k_lo + lane; key0 < k_hi; key0 += 256) {
       u32x4 kr[4][8];
 #pragma unroll
@@ -427,9 +508,6 @@ __device__ __forceinline__ void attn_pair(rsrc_t qrs, unsigned qoff, rsrc_t kvrs
       l += e;
     }
     l = wave_sum(l);
-  }
-  __syncthreads();
-  if (wave < nw) {
     for (int key0 = k_lo + kg; key0 < k_hi; key0 += 64) {
       u32x4 vr[8]; float pk[8];
 #pragma unroll
@@ -447,10 +525,30 @@ __device__ __forceinline__ void attn_pair(rsrc_t qrs, unsigned qoff, rsrc_t kvrs
           acc[2 * i + 1] += pk[u] * __uint_as_float(vr[u][i] & 0xffff0000u);
         }
     }
+  }
 #pragma unroll
-    for (int o = 8; o < 64; o <<= 1)
+  for (int o = 8; o < 64; o <<= 1)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], o, 64);
+    for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], o, 64);
+}
+
+template <int AUX>
+__device__ __forceinline__ void attn_pair(rsrc_t qrs, unsigned qoff, rsrc_t kvrs, unsigned koff, unsigned voff, unsigned ldb, int Tk,
+                                          const uint8_t* km, float scale, rsrc_t ors, unsigned ooff, float* probs, int wave, int lane) {
+  const int nw = Tk >= 256 ? NWAVE : 1;
+  const int per = (Tk + nw - 1) / nw;
+  const int k_lo = wave * per, k_hi = wave < nw ? min(Tk, k_lo + per) : k_lo;
+  float m = -INFINITY, l = 0.f;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  const int kg = lane >> 3, dc = lane & 7;
+  if (wave < nw) {
+    // a wave reads back only the probabilities it wrote itself (LDS operations of one wave execute in order)
+    if (per <= 64) attn_share<AUX, 1>(qrs, qoff, kvrs, koff, voff, ldb, k_lo, k_hi, km, scale, probs, lane, m, l, acc);
+    else if (per <= 128) attn_share<AUX, 2>(qrs, qoff, kvrs, koff, voff, ldb, k_lo, k_hi, km, scale, probs, lane, m, l, acc);
+    else if (per <= 192) attn_share<AUX, 3>(qrs, qoff, kvrs, koff, voff, ldb, k_lo, k_hi, km, scale, probs, lane, m, l, acc);
+    else attn_share<AUX, 0>(qrs, qoff, kvrs, koff, voff, ldb, k_lo, k_hi, km, scale, probs, lane, m, l, acc);
   }
   if (nw > 1) {
     float* pacc = probs + Tk;                          // [4][64]
@@ -490,18 +588,25 @@ __device__ __forceinline__ void attn_pair(rsrc_t qrs, unsigned qoff, rsrc_t kvrs
 
 __device__ __forceinline__ int wave_of(int tid) { return __builtin_amdgcn_readfirstlane(tid >> 6); }
 
+#define TR(K_) do { if (p.trace && wg == p.trace_wg && tid == 0) p.trace[bar.ph * 8 + (K_)] = wall_clock64(); } while (0)
 #define END_PHASE(PREFETCH)                                     \
+  TR(3);                                                        \
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              \
+  TR(4);                                                        \
   bar_arrive(bar);                                              \
   { PREFETCH; }                                                 \
-  if (!bar_wait(bar, &s_bad)) return;
+  TR(5 - 8);                                                    \
+  if (!bar_wait(bar, &s_bad)) return;                           \
+  TR(0);
 
 __global__ __launch_bounds__(NTHR) void decoder_step_kernel(DecP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* xs = (bf16_t*)smem;                                   // [R][max(d, F)] bf16
   char* wbig = smem + p.xs_bytes + wave_of(threadIdx.x) * WBIG;                         // this wave's prefetch slots
   char* wsml = smem + p.xs_bytes + NWAVE * WBIG + wave_of(threadIdx.x) * WSMALL;
-  float* probs = (float*)(smem + p.xs_bytes + NWAVE * (WBIG + WSMALL));   // [max(S, t + 1)] + 4 * 64 + 8
+  float* lnp = (float*)(smem + p.xs_bytes + NWAVE * (WBIG + WSMALL));     // gamma[1024] | beta[1024] of the next LayerNorm
+  float* biasl = lnp + 2048;                                              // bias of this workgroup's (<= 16) output columns
+  float* probs = biasl + 64;                                              // [max(S, t + 1)] + 4 * 64 + 8
   __shared__ float part[NWAVE][32];
   __shared__ int s_bad;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -521,26 +626,34 @@ __global__ __launch_bounds__(NTHR) void decoder_step_kernel(DecP p) {
   const int Tk_self = p.t + 1;
 
   const unsigned wb_dd = (unsigned)(d * d * 2), wb_fd = (unsigned)(F * d * 2);
-  w_issue<4>(wbig, mkrs(p.layers[0].w_kvq, 3 * wb_dd), 3 * d, d, (wg * NWAVE + wave) * 4, lane);
+  const int c1 = wg * NWAVE + wave, c4 = c1 * 4;               // this wave's first column in a 1- / 4-column-per-wave phase
+  // What is in flight across a barrier (issued between its arrive and its wait, retired inside the wait): the next projection's
+  // weight tile (per-wave slots), its bias values and, before a LayerNorm phase, gamma | beta (workgroup-shared slots).
+  {
+    const vacnic_decoder_layer l0 = p.layers[0];
+    w_issue<4>(wbig, mkrs(l0.w_kvq, 3 * wb_dd), 3 * d, d, c4, lane);
+    bias_issue(biasl, l0.b_kvq, 3 * d, wg * 16, 16, wave, lane);
+  }
 
   for (int li = 0; li < p.L; ++li) {
-    const vacnic_decoder_layer& ly = p.layers[li];
+    const vacnic_decoder_layer ly = p.layers[li];
     const unsigned lay_b = (unsigned)li * (unsigned)R * row_b;
     // ---- P1: k|v|q of position t, in place in the cache (k|v at row t, q parked in the first d columns of row t + 1)
     if (li == 0) {
       stage_plain(rs_h0, xs, R, d, tid);
+      w_wait();
     } else {
-      const vacnic_decoder_layer& pv = p.layers[li - 1];
       const rsrc_t hn = (nln & 1) ? rs_hb1 : rs_hb0;
-      stage_ln(rs_o, hcur, pv.ln_final_g, pv.ln_final_b, hn, wg == 0, xs, R, d, p.eps, wave, lane);
+      stage_ln(rs_o, hcur, lnp, hn, wg == 0, xs, R, d, p.eps, wave, lane);
       hcur = hn; ++nln;
     }
     __syncthreads();
+    TR(1);
     {
       const OutD out_c = {rs_cache, lay_b + (unsigned)p.t * (unsigned)(2 * d) * 2u, row_b};
-      gemv_phase<4>(wbig, mkrs(ly.w_kvq, 3 * wb_dd), ly.b_kvq, 3 * d, d, VACNIC_ACT_NONE, out_c, xs, R, G, wg, wave, lane);
+      gemv_phase<4>(wbig, mkrs(ly.w_kvq, 3 * wb_dd), ly.b_kvq, biasl, 3 * d, d, VACNIC_ACT_NONE, out_c, xs, R, G, wg, wave, lane);
     }
-    END_PHASE(w_issue<1>(wsml, mkrs(ly.w_so, wb_dd), d, d, wg * NWAVE + wave, lane))
+    END_PHASE(w_issue<1>(wsml, mkrs(ly.w_so, wb_dd), d, d, c1, lane); bias_issue(biasl, ly.b_so, d, wg * 4, 4, wave, lane))
     // ---- P2: self-attention over cache rows 0..t
     for (int pr = wg; pr < R * H; pr += G) {
       const int r = pr / H, h = pr - r * H;
@@ -553,17 +666,20 @@ __global__ __launch_bounds__(NTHR) void decoder_step_kernel(DecP p) {
     // ---- P3: self-attention output projection
     stage_plain(rs_ctx, xs, R, d, tid);
     __syncthreads();
-    gemv_phase<1>(wsml, mkrs(ly.w_so, wb_dd), ly.b_so, d, d, VACNIC_ACT_NONE, out_o, xs, R, G, wg, wave, lane);
-    END_PHASE(w_issue<1>(wsml, mkrs(ly.w_cq, wb_dd), d, d, wg * NWAVE + wave, lane))
+    TR(1);
+    gemv_phase<1>(wsml, mkrs(ly.w_so, wb_dd), ly.b_so, biasl, d, d, VACNIC_ACT_NONE, out_o, xs, R, G, wg, wave, lane);
+    END_PHASE(w_issue<1>(wsml, mkrs(ly.w_cq, wb_dd), d, d, c1, lane); bias_issue(biasl, ly.b_cq, d, wg * 4, 4, wave, lane);
+              ln_issue(lnp, ly.ln_self_g, ly.ln_self_b, d, wave, lane))
     // ---- P4: post-LN of the self-attention block, cross-attention query
     {
       const rsrc_t hn = (nln & 1) ? rs_hb1 : rs_hb0;
-      stage_ln(rs_o, hcur, ly.ln_self_g, ly.ln_self_b, hn, wg == 0, xs, R, d, p.eps, wave, lane);
+      stage_ln(rs_o, hcur, lnp, hn, wg == 0, xs, R, d, p.eps, wave, lane);
       hcur = hn; ++nln;
     }
     __syncthreads();
-    gemv_phase<1>(wsml, mkrs(ly.w_cq, wb_dd), ly.b_cq, d, d, VACNIC_ACT_NONE, out_q, xs, R, G, wg, wave, lane);
-    END_PHASE(w_issue<1>(wsml, mkrs(ly.w_co, wb_dd), d, d, wg * NWAVE + wave, lane))
+    TR(1);
+    gemv_phase<1>(wsml, mkrs(ly.w_cq, wb_dd), ly.b_cq, biasl, d, d, VACNIC_ACT_NONE, out_q, xs, R, G, wg, wave, lane);
+    END_PHASE(w_issue<1>(wsml, mkrs(ly.w_co, wb_dd), d, d, c1, lane); bias_issue(biasl, ly.b_co, d, wg * 4, 4, wave, lane))
     // ---- P5: cross-attention over the encoder K/V
     {
       const unsigned kv_rows = ly.cross_bs == 0 ? 1u : (unsigned)R;
@@ -580,23 +696,29 @@ __global__ __launch_bounds__(NTHR) void decoder_step_kernel(DecP p) {
     // ---- P6: cross-attention output projection
     stage_plain(rs_ctx, xs, R, d, tid);
     __syncthreads();
-    gemv_phase<1>(wsml, mkrs(ly.w_co, wb_dd), ly.b_co, d, d, VACNIC_ACT_NONE, out_o, xs, R, G, wg, wave, lane);
-    END_PHASE(w_issue<4>(wbig, mkrs(ly.w_fc1, wb_fd), F, d, (wg * NWAVE + wave) * 4, lane))
+    TR(1);
+    gemv_phase<1>(wsml, mkrs(ly.w_co, wb_dd), ly.b_co, biasl, d, d, VACNIC_ACT_NONE, out_o, xs, R, G, wg, wave, lane);
+    END_PHASE(w_issue<4>(wbig, mkrs(ly.w_fc1, wb_fd), F, d, c4, lane); bias_issue(biasl, ly.b_fc1, F, wg * 16, 16, wave, lane);
+              ln_issue(lnp, ly.ln_cross_g, ly.ln_cross_b, d, wave, lane))
     // ---- P7: post-LN of the cross-attention block, fc1 + GELU
     {
       const rsrc_t hn = (nln & 1) ? rs_hb1 : rs_hb0;
-      stage_ln(rs_o, hcur, ly.ln_cross_g, ly.ln_cross_b, hn, wg == 0, xs, R, d, p.eps, wave, lane);
+      stage_ln(rs_o, hcur, lnp, hn, wg == 0, xs, R, d, p.eps, wave, lane);
       hcur = hn; ++nln;
     }
     __syncthreads();
-    gemv_phase<4>(wbig, mkrs(ly.w_fc1, wb_fd), ly.b_fc1, F, d, VACNIC_ACT_GELU, out_f, xs, R, G, wg, wave, lane);
-    END_PHASE(w2_issue(wbig, mkrs(ly.w_fc2, wb_fd), d, F, wg * 4, wave, lane))
+    TR(1);
+    gemv_phase<4>(wbig, mkrs(ly.w_fc1, wb_fd), ly.b_fc1, biasl, F, d, VACNIC_ACT_GELU, out_f, xs, R, G, wg, wave, lane);
+    END_PHASE(w2_issue(wbig, mkrs(ly.w_fc2, wb_fd), d, F, wg * 4, wave, lane); bias_issue(biasl, ly.b_fc2, d, wg * 4, 4, wave, lane))
     // ---- P8: fc2
     stage_plain(rs_f, xs, R, F, tid);
     __syncthreads();
-    gemv2_phase(wbig, mkrs(ly.w_fc2, wb_fd), ly.b_fc2, d, F, out_o, xs, R, G, wg, wave, lane, part);
+    TR(1);
+    gemv2_phase(wbig, mkrs(ly.w_fc2, wb_fd), ly.b_fc2, biasl, d, F, out_o, xs, R, G, wg, wave, lane, part);
     if (li + 1 < p.L) {
-      END_PHASE(w_issue<4>(wbig, mkrs(p.layers[li + 1].w_kvq, 3 * wb_dd), 3 * d, d, (wg * NWAVE + wave) * 4, lane))
+      const vacnic_decoder_layer nx = p.layers[li + 1];
+      END_PHASE(w_issue<4>(wbig, mkrs(nx.w_kvq, 3 * wb_dd), 3 * d, d, c4, lane); bias_issue(biasl, nx.b_kvq, 3 * d, wg * 16, 16, wave, lane);
+                ln_issue(lnp, ly.ln_final_g, ly.ln_final_b, d, wave, lane))
     }
   }
   // exit: the last workgroup out clears the barrier state (stream order makes it visible to the next launch)
@@ -647,8 +769,9 @@ extern "C" int vacnic_decoder_step(const vacnic_decoder_step_args* a, void* stre
   const int64_t kmax = a->d > a->F ? a->d : a->F;
   p.xs_bytes = (unsigned)(a->R * kmax * 2);
   p.eps = a->eps; p.scale = a->scale;
+  p.trace = (unsigned long long*)a->trace; p.trace_wg = (int)a->trace_wg;
   const int64_t tkmax = a->S > a->t + 1 ? a->S : a->t + 1;
-  const size_t lds = (size_t)p.xs_bytes + (size_t)NWAVE * (WBIG + WSMALL) + (size_t)(tkmax + NWAVE * 64 + 8) * 4;
+  const size_t lds = (size_t)p.xs_bytes + (size_t)NWAVE * (WBIG + WSMALL) + (size_t)(2048 + 64) * 4 + (size_t)(tkmax + NWAVE * 64 + 8) * 4;
   VCHECK(lds <= 150 * 1024, VACNIC_UNSUPPORTED, "decoder_step: LDS budget");
   static size_t lds_set = 0;
   if (lds > 65536 - 1024 && lds > lds_set) {

@@ -87,6 +87,7 @@ class CachedDecoder:
         self.step_kernel = (os.environ.get("VACNIC_DECODE_PER_OP", "0") != "1" and rows <= 8 and d <= 1024 and d % 8 == 0 and F <= 4096
                             and F % 8 == 0 and self.H * 64 == d and max_length <= 8191)
         self.step_table = None
+        self.trace, self.trace_wg = None, 0       # tools/decstep_trace.py: per-phase time stamps of one workgroup
         if self.step_kernel:
             self.sync = torch.zeros(int(_lib.lib.vacnic_decoder_step_sync_bytes()) // 4, device=dev, dtype=torch.int32)
             self.hbuf = [torch.zeros((rows, d), device=dev, dtype=BF16) for _ in range(2)]
@@ -144,7 +145,8 @@ class CachedDecoder:
                          h0=h.data_ptr(), hbuf0=self.hbuf[0].data_ptr(), hbuf1=self.hbuf[1].data_ptr(), obuf=self.obuf.data_ptr(),
                          ctx=self.ctxb.data_ptr(), qbuf=self.qbuf.data_ptr(), fbuf=self.fbuf.data_ptr(), enc_mask=self.enc_mask.data_ptr(),
                          sync=self.sync.data_ptr(), L=self.L, R=self.rows, d=self.d, H=self.H, F=self.F, S=self.S, t=t, Tmax=self.Tmax,
-                         eps=lay.final_layer_norm.eps, scale=0.125)
+                         eps=lay.final_layer_norm.eps, scale=0.125, trace=self.trace.data_ptr() if self.trace is not None else None,
+                         trace_wg=self.trace_wg)
         return self.obuf, self.hbuf[self.L & 1]
 
     def check_step_kernel(self):
@@ -368,7 +370,8 @@ def generate(model, input_ids=None, attention_mask=None, num_beams=1, max_length
     if model.arena is None:
         raise RuntimeError("call model.finalize(device) first")
     was_training = model.training
-    model.eval()
+    if was_training:
+        model.eval()                              # (walks ~1000 modules: 1 ms — skipped when the model already is in eval mode)
     eos, pad, start = cfg.eos_token_id, cfg.pad_token_id, cfg.decoder_start_token_id
     if forced_eos_token_id == "config":
         forced_eos_token_id = eos                     # BartConfig default forced_eos_token_id=2
