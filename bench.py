@@ -204,12 +204,12 @@ def target_gemm_leg():
     return out
 
 
-def decode_leg(model, cfg, n=4):
+def decode_leg(model, cfg, n=6):
     """BASELINE configs[4]: captions/sec at batch 1, beam 5, max_length 50, length_penalty 2.0 (seed 42 inputs), on the model the
     step just trained (eval mode, no guide needed).  min_length 49 forces full-length captions (random-init weights would emit
     EOS at once): the worst case."""
     from vacnic_amd import kernels as K, synthetic
-    from vacnic_amd.models.clip_vit import extract_clip_img_feat
+    from vacnic_amd.models.clip_vit import graphed_clip_img_feat
     from vacnic_amd.training import to_device
     from vacnic_amd import streams
     streams.enable(False)
@@ -221,7 +221,7 @@ def decode_leg(model, cfg, n=4):
             torch.cuda.synchronize(); t0 = time.perf_counter()
             mask, _ = K.prep_ids(b["article_ids"], 1)
             nmask, _ = K.prep_ids(b["names_art_ids"], 1)
-            _, cls = extract_clip_img_feat(model.clip_model, b["img_tensor"])
+            _, cls = graphed_clip_img_feat(model.clip_model)(b["img_tensor"])
             out = model.generate(input_ids=b["article_ids"], attention_mask=mask, num_beams=5, max_length=50, length_penalty=2.0,
                                  min_length=49, image_features=cls, face_features=b["face_emb"], face_mask=K.face_mask(b["face_emb"]),
                                  name_ids=b["names_art_ids"], name_mask=nmask, add_ner_ffn=True)

@@ -348,8 +348,11 @@ int vacnic_beam_step(const vacnic_beam_state* st, const float* top_val, const in
  *   hbuf/obuf/ctx/qbuf ([R][d]) and fbuf ([R][F]): scratch.  On return the last layer's un-normalised block output is obuf and
  *            its residual is hbuf[L & 1]; final_layer_norm of the last layer is left to the consumer (vacnic_gemv_ln_bf16 with
  *            the LM head).
- *   sync     vacnic_decoder_step_sync_bytes() bytes, zeroed ONCE by the caller; word [sync_bytes / 4 - 32] is an error flag the
- *            kernel raises (and leaves) if a grid barrier times out — check it when the results are read back.
+ *   sync     vacnic_decoder_step_sync_bytes() bytes, zeroed ONCE by the caller; word [sync_bytes / 4 - 64] is an error flag the
+ *            kernel raises (and leaves) if a wait times out — check it when the results are read back.
+ *   slots    vacnic_decoder_step_slots_bytes() bytes, zeroed ONCE by the caller: the phases hand their results over through
+ *            tagged 16-byte units in this buffer (no grid barriers; needs max(d / 4, ffn / 16) <= 256 co-resident workgroups and
+ *            d, ffn multiples of 16).  NULL selects the grid-barrier variant (kept as the A/B baseline).
  */
 typedef struct {
   const void *w_kvq, *w_so, *w_cq, *w_co, *w_fc1, *w_fc2;
@@ -364,6 +367,7 @@ typedef struct {
   void* hbuf[2]; void* obuf; void* ctx; void* qbuf; void* fbuf;
   const uint8_t* enc_mask;        /* uint8 [R][S], 0 = masked source position; may be NULL */
   uint32_t* sync;
+  void* slots;
   int64_t L, R, d, H, F, S, t, Tmax;
   float eps, scale;
   uint64_t* trace; int64_t trace_wg;   /* profiling aid, normally NULL: 100 MHz time stamps of workgroup trace_wg, uint64 [8 L][8]
@@ -371,6 +375,7 @@ typedef struct {
                                           [5] arrived at the barrier + next weights issued) */
 } vacnic_decoder_step_args;
 int64_t vacnic_decoder_step_sync_bytes(void);
+int64_t vacnic_decoder_step_slots_bytes(void);
 int vacnic_decoder_step(const vacnic_decoder_step_args* a, void* stream);
 /* dst[r] = src[idx[r]] for rows of row_bytes (multiple of 16): KV-cache beam reorder (_reorder_cache, MFULL:2066-2074). */
 int vacnic_gather_rows(const void* src, void* dst, const int64_t* idx, int64_t rows, int64_t row_bytes, void* stream);

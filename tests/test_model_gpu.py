@@ -751,8 +751,9 @@ def test_whole_step_hipgraph_replays_like_eager():
         streams.enable(False)
 
 
+@pytest.mark.parametrize("variant", ["slots", "barrier"])
 @pytest.mark.parametrize("case", ["bart_base_shape", "bart_large_shape"])
-def test_decoder_step_kernel_matches_per_op_path(case, monkeypatch):
+def test_decoder_step_kernel_matches_per_op_path(case, variant, monkeypatch):
     """the persistent decoder-step kernel (all layers of a position in ONE launch, grid barriers between the
     phases) against the kernel-per-op chain it replaces (gemv_ln / skinny GEMM / single-query attention), including beam reorders
     between positions, a masked source and both attention key-split modes (S < 256: one wave per (row, head); S >= 256: four).
@@ -782,8 +783,11 @@ def test_decoder_step_kernel_matches_per_op_path(case, monkeypatch):
     mask = torch.ones(B, S, dtype=torch.uint8)
     mask[:, S - 5:] = 0                                        # padded source tail
     mask = mask.cuda()
+    # the two exchange mechanisms of the step kernel: tagged slots (default, no grid barriers) and grid barriers
+    monkeypatch.setenv("VACNIC_DECODE_BARRIER", "1" if variant == "barrier" else "0")
     fast = Gn.CachedDecoder(model, R, S, Tmax, reorders=True)
     assert fast.step_kernel, "the step kernel must be the default for <= 8 rows"
+    assert (fast.slots is not None) == (variant == "slots")
     monkeypatch.setenv("VACNIC_DECODE_PER_OP", "1")
     ref = Gn.CachedDecoder(model, R, S, Tmax, reorders=True)
     assert not ref.step_kernel

@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from vacnic_amd import kernels as K, synthetic
 from vacnic_amd.config import bart_large_vit_l14
-from vacnic_amd.models.clip_vit import extract_clip_img_feat
+from vacnic_amd.models.clip_vit import extract_clip_img_feat, graphed_clip_img_feat
 from vacnic_amd.training import build_models, to_device
 
 
@@ -24,7 +24,7 @@ def main():
         torch.cuda.synchronize(); t0 = time.perf_counter()
         mask, _ = K.prep_ids(b["article_ids"], 1)
         nmask, _ = K.prep_ids(b["names_art_ids"], 1)
-        _, cls = extract_clip_img_feat(clip_model, b["img_tensor"])
+        _, cls = graphed_clip_img_feat(clip_model)(b["img_tensor"])
         out = model.generate(input_ids=b["article_ids"], attention_mask=mask, num_beams=5, max_length=50, length_penalty=2.0,
                              min_length=49,      # random-init weights emit EOS at once; force full-length captions (worst case)
                              image_features=cls, face_features=b["face_emb"], face_mask=K.face_mask(b["face_emb"]),

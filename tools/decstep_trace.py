@@ -28,6 +28,18 @@ with torch.no_grad():
         dec.step(ids, 30)
         torch.cuda.synchronize()
         tr = dec.trace.cpu().view(-1, 8).double() / 100.0          # us
+        if dec.slots is not None:
+            print(f"workgroup {wg} (slot variant): kernel span {(tr[8 * L - 1, 3] - tr[0, 1]).item():.1f} us over {8 * L} phases")
+            print("  phase            wait+gather   compute+pack    total   (attention phases: pair workgroups only)")
+            for k in range(8):
+                rows = [ph for ph in range(8, 8 * L) if ph % 8 == k and tr[ph, 3] > 0 and tr[ph, 1] > 0]
+                if not rows:
+                    continue
+                prev = lambda ph: max(tr[q, 3].item() for q in range(max(0, ph - 3), ph))
+                ga = sum(tr[ph, 1].item() - prev(ph) for ph in rows) / len(rows)
+                co = sum((tr[ph, 3] - tr[ph, 1]).item() for ph in rows) / len(rows)
+                print(f"  {names[k]:14s} {ga:11.2f} {co:14.2f} {ga + co:8.2f}")
+            continue
         print(f"workgroup {wg}: kernel span {(tr[8 * L - 1, 3] - tr[0, 1]).item():.1f} us over {8 * L} phases")
         print("  phase            stage   compute+store  store-ack  arrive+issue  barrier-wait   total")
         for k in range(8):

@@ -123,7 +123,7 @@ DecoderLayer = _struct("vacnic_decoder_layer", [
 
 DecoderStepArgs = _struct("vacnic_decoder_step_args", [
     ("layers", vp), ("cache", vp), ("h0", vp), ("hbuf0", vp), ("hbuf1", vp), ("obuf", vp), ("ctx", vp), ("qbuf", vp), ("fbuf", vp),
-    ("enc_mask", vp), ("sync", vp),
+    ("enc_mask", vp), ("sync", vp), ("slots", vp),
     ("L", i64), ("R", i64), ("d", i64), ("H", i64), ("F", i64), ("S", i64), ("t", i64), ("Tmax", i64), ("eps", f32), ("scale", f32),
     ("trace", vp), ("trace_wg", i64)])
 
@@ -170,7 +170,7 @@ _PLAIN_FNS = {
     "vacnic_beam_init": [C.POINTER(BeamState), i32, vp],
     "vacnic_beam_step": [C.POINTER(BeamState), vp, vp, i32, i32, vp],
 }
-EXPORTED = sorted(list(_STRUCT_FNS) + list(_PLAIN_FNS) + ["vacnic_last_error_string", "vacnic_version", "vacnic_decoder_step_sync_bytes"])
+EXPORTED = sorted(list(_STRUCT_FNS) + list(_PLAIN_FNS) + ["vacnic_last_error_string", "vacnic_version", "vacnic_decoder_step_sync_bytes", "vacnic_decoder_step_slots_bytes"])
 
 for _name, _st in _STRUCT_FNS.items():
     _fn = getattr(lib, _name)          # AttributeError here = stale .so: fail loudly
@@ -186,6 +186,8 @@ lib.vacnic_version.restype = C.c_int
 lib.vacnic_version.argtypes = []
 lib.vacnic_decoder_step_sync_bytes.restype = C.c_int64
 lib.vacnic_decoder_step_sync_bytes.argtypes = []
+lib.vacnic_decoder_step_slots_bytes.restype = C.c_int64
+lib.vacnic_decoder_step_slots_bytes.argtypes = []
 
 _VALUE_ERRORS = (1, 2, 3)   # bad shape / dtype / alignment -> ValueError like the reference's shape checks
 

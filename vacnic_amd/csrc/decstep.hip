@@ -50,6 +50,7 @@ struct DecP {
   unsigned cache_bytes, xs_bytes;
   float eps, scale;
   unsigned long long* trace; int trace_wg;    // profiling aid: 100 MHz time stamps of one workgroup, [phase][8]
+  char* slots;                                // tagged-slot exchange buffers (slot variant)
 };
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
@@ -191,10 +192,10 @@ __device__ __forceinline__ float bfly8(float (&acc)[8], int lane, int& idx, bool
 }
 #undef VAC_BFLY
 
-// one wave: C output columns n0 .. n0+C-1 for all R rows; x (bf16, LDS) [R][K]
+// one wave: the dot products of C weight rows (this wave's prefetch slots) with all R rows of x (bf16, LDS, [R][K]); after the
+// reduce-scatter butterfly `owner` lanes hold the sum of (row idx / C, column idx % C)
 template <int C>
-__device__ __forceinline__ void gemv_tile(const char* wl, const bf16_t* xs, int R, int N, int K, int n0, const float* bias, const float* biasl,
-                                          int act, const OutD& o, int lane) {
+__device__ __forceinline__ float gemv_reduce(const char* wl, const bf16_t* xs, int R, int K, int lane, int& idx, bool& owner) {
   constexpr int NV = MR * C;
   float acc[NV];
 #pragma unroll
@@ -220,9 +221,16 @@ __device__ __forceinline__ void gemv_tile(const char* wl, const bf16_t* xs, int 
       }
     }
   }
-  int idx; bool owner; float v;
-  if constexpr (C == 4) v = bfly32(acc, lane, idx, owner);
-  else v = bfly8(acc, lane, idx, owner);
+  if constexpr (C == 4) return bfly32(acc, lane, idx, owner);
+  else return bfly8(acc, lane, idx, owner);
+}
+
+// one wave: C output columns n0 .. n0+C-1 for all R rows
+template <int C>
+__device__ __forceinline__ void gemv_tile(const char* wl, const bf16_t* xs, int R, int N, int K, int n0, const float* bias, const float* biasl,
+                                          int act, const OutD& o, int lane) {
+  int idx; bool owner;
+  float v = gemv_reduce<C>(wl, xs, R, K, lane, idx, owner);
   if (owner) {
     const int m = idx / C, c = idx % C, n = n0 + c;
     if (m < R && n < N) {
@@ -396,13 +404,23 @@ __device__ __forceinline__ void stage_ln(rsrc_t osrc, rsrc_t hsrc, const float* 
 // One wave's share [k_lo, k_hi) of the keys.  KU > 0: the share fits 64 * KU keys and EVERY load of the phase (q, the key rows,
 // the value rows) is issued before the first is consumed — the phase is a chain of dependent ~2 us round trips otherwise
 // (q -> keys -> values per 64 keys: 12 us for a 133-key share); the arithmetic and its order are unchanged.  KU == 0: any length.
+// (slot variant) qlds: the query as 64 bf16 in LDS instead of qrs; knew / vnew: the key / value row of position t_new in LDS — that
+// row of the cache is being written by other workgroups in this launch and is not read.
+struct AttnNew { const bf16_t* qlds; const bf16_t* knew; const bf16_t* vnew; int t_new; };
+
 template <int AUX, int KU>
 __device__ __forceinline__ void attn_share(rsrc_t qrs, unsigned qoff, rsrc_t kvrs, unsigned koff, unsigned voff, unsigned ldb, int k_lo, int k_hi,
-                                           const uint8_t* km, float scale, float* probs, int lane, float& m, float& l, float (&acc)[8]) {
+                                           const uint8_t* km, float scale, float* probs, int lane, float& m, float& l, float (&acc)[8],
+                                           const AttnNew& an) {
   const int kg = lane >> 3, dc = lane & 7;
   u32x4 qr[8];
+  if (an.qlds) {
 #pragma unroll
-  for (int c = 0; c < 8; ++c) qr[c] = cld(qrs, qoff + c * 16);
+    for (int c = 0; c < 8; ++c) qr[c] = *(const u32x4*)(an.qlds + c * 8);
+  } else {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) qr[c] = cld(qrs, qoff + c * 16);
+  }
   if constexpr (KU > 0) {
     u32x4 kr[KU][8], vr[KU][8];
 #pragma unroll
@@ -419,6 +437,19 @@ __device__ __forceinline__ void attn_share(rsrc_t qrs, unsigned qoff, rsrc_t kvr
         const int key = k_lo + kg + 64 * it + 8 * u;
         vr[it][u] = __builtin_amdgcn_raw_buffer_load_b128(kvrs, voff + (unsigned)(key < k_hi ? key : k_lo) * ldb + dc * 16, 0, AUX);
       }
+    if (an.t_new >= 0) {
+#pragma unroll
+      for (int u = 0; u < KU; ++u)
+        if (k_lo + lane + 64 * u == an.t_new) {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) kr[u][c] = *(const u32x4*)(an.knew + c * 8);
+        }
+#pragma unroll
+      for (int it = 0; it < KU; ++it)
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (k_lo + kg + 64 * it + 8 * u == an.t_new) vr[it][u] = *(const u32x4*)(an.vnew + dc * 8);
+    }
     float qf[64];
 #pragma unroll
     for (int c = 0; c < 8; ++c)
@@ -481,6 +512,10 @@ __device__ __forceinline__ void attn_share(rsrc_t qrs, unsigned qoff, rsrc_t kvr
         const unsigned ro = koff + (unsigned)(key < k_hi ? key : key0) * ldb;
 #pragma unroll
         for (int c = 0; c < 8; ++c) kr[u][c] = __builtin_amdgcn_raw_buffer_load_b128(kvrs, ro + c * 16, 0, AUX);
+        if (key == an.t_new) {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) kr[u][c] = *(const u32x4*)(an.knew + c * 8);
+        }
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -515,6 +550,7 @@ __device__ __forceinline__ void attn_share(rsrc_t qrs, unsigned qoff, rsrc_t kvr
         const int key = key0 + 8 * u;
         const bool ok = key < k_hi;
         vr[u] = __builtin_amdgcn_raw_buffer_load_b128(kvrs, voff + (unsigned)(ok ? key : key0) * ldb + dc * 16, 0, AUX);
+        if (key == an.t_new) vr[u] = *(const u32x4*)(an.vnew + dc * 8);
         pk[u] = ok ? probs[key] : 0.f;
       }
 #pragma unroll
@@ -532,9 +568,11 @@ __device__ __forceinline__ void attn_share(rsrc_t qrs, unsigned qoff, rsrc_t kvr
     for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], o, 64);
 }
 
+// res8 == nullptr: the 64 outputs go to ooff of ors (coherent store); else lanes dc = 0..7 of wave 0 (kg == 0) leave their 8 values there
 template <int AUX>
 __device__ __forceinline__ void attn_pair(rsrc_t qrs, unsigned qoff, rsrc_t kvrs, unsigned koff, unsigned voff, unsigned ldb, int Tk,
-                                          const uint8_t* km, float scale, rsrc_t ors, unsigned ooff, float* probs, int wave, int lane) {
+                                          const uint8_t* km, float scale, rsrc_t ors, unsigned ooff, float* probs, int wave, int lane,
+                                          const AttnNew& an = AttnNew{nullptr, nullptr, nullptr, -1}, float* res8 = nullptr) {
   const int nw = Tk >= 256 ? NWAVE : 1;
   const int per = (Tk + nw - 1) / nw;
   const int k_lo = wave * per, k_hi = wave < nw ? min(Tk, k_lo + per) : k_lo;
@@ -545,10 +583,10 @@ __device__ __forceinline__ void attn_pair(rsrc_t qrs, unsigned qoff, rsrc_t kvrs
   const int kg = lane >> 3, dc = lane & 7;
   if (wave < nw) {
     // a wave reads back only the probabilities it wrote itself (LDS operations of one wave execute in order)
-    if (per <= 64) attn_share<AUX, 1>(qrs, qoff, kvrs, koff, voff, ldb, k_lo, k_hi, km, scale, probs, lane, m, l, acc);
-    else if (per <= 128) attn_share<AUX, 2>(qrs, qoff, kvrs, koff, voff, ldb, k_lo, k_hi, km, scale, probs, lane, m, l, acc);
-    else if (per <= 192) attn_share<AUX, 3>(qrs, qoff, kvrs, koff, voff, ldb, k_lo, k_hi, km, scale, probs, lane, m, l, acc);
-    else attn_share<AUX, 0>(qrs, qoff, kvrs, koff, voff, ldb, k_lo, k_hi, km, scale, probs, lane, m, l, acc);
+    if (per <= 64) attn_share<AUX, 1>(qrs, qoff, kvrs, koff, voff, ldb, k_lo, k_hi, km, scale, probs, lane, m, l, acc, an);
+    else if (per <= 128) attn_share<AUX, 2>(qrs, qoff, kvrs, koff, voff, ldb, k_lo, k_hi, km, scale, probs, lane, m, l, acc, an);
+    else if (per <= 192) attn_share<AUX, 3>(qrs, qoff, kvrs, koff, voff, ldb, k_lo, k_hi, km, scale, probs, lane, m, l, acc, an);
+    else attn_share<AUX, 0>(qrs, qoff, kvrs, koff, voff, ldb, k_lo, k_hi, km, scale, probs, lane, m, l, acc, an);
   }
   if (nw > 1) {
     float* pacc = probs + Tk;                          // [4][64]
@@ -581,8 +619,13 @@ __device__ __forceinline__ void attn_pair(rsrc_t qrs, unsigned qoff, rsrc_t kvrs
   }
   if (wave == 0 && kg == 0) {
     const float inv = 1.f / l;
-    cst((u32x4){pack2bf(acc[0] * inv, acc[1] * inv), pack2bf(acc[2] * inv, acc[3] * inv), pack2bf(acc[4] * inv, acc[5] * inv),
-                pack2bf(acc[6] * inv, acc[7] * inv)}, ors, ooff + dc * 16);
+    if (res8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) res8[j] = acc[j] * inv;
+    } else {
+      cst((u32x4){pack2bf(acc[0] * inv, acc[1] * inv), pack2bf(acc[2] * inv, acc[3] * inv), pack2bf(acc[4] * inv, acc[5] * inv),
+                  pack2bf(acc[6] * inv, acc[7] * inv)}, ors, ooff + dc * 16);
+    }
   }
 }
 
@@ -734,9 +777,406 @@ __global__ __launch_bounds__(NTHR) void decoder_step_kernel(DecP p) {
   }
 }
 
+
+// =====================================================================================================================
+// Slot variant (the default): no barriers at all.  A phase's producers hand their results to the consumers through TAGGED
+// SLOTS in HBM: a slot is a run of 16-byte units {6 bf16 values, 32-bit tag}, written with one coherent 16-byte store per unit
+// and NO wait for the acknowledgement; a consumer thread polls "its" producer's slot until every unit carries the tag of
+// (this launch, this phase) and scatters the values into the workgroup's LDS copy of the activation.  The data IS the
+// signal, so a phase boundary costs one store-to-visible latency plus one poll round trip (~1.5 us) instead of store
+// acknowledgement + two dependent atomics + flag poll + reload (~4 us with the barrier).  Tag = nonce * 1024 + phase, nonce =
+// a per-buffer launch counter (read by everybody at the start, bumped by workgroup 0 at its exit — which cannot happen before
+// every workgroup has produced its last phase), so a stale slot can never match.  A slot array is reused once per layer:
+// whoever produces phase X of layer l+1 has consumed data that transitively required every workgroup to be past its read of
+// (l, X).  The residual stream h never leaves the chip: every workgroup normalises all rows anyway and keeps h in LDS.
+//   slot arrays (bytes): 6 GEMV outputs x 256 workgroups x 384  |  2 attention outputs x 128 (row, head) pairs x 192
+constexpr unsigned SLOT_STRIDE = 384, CTX_STRIDE = 192, SLOT_ARR = 256 * SLOT_STRIDE, CTX_ARR0 = 6 * SLOT_ARR, CTX_ARR = 128 * CTX_STRIDE;
+constexpr unsigned SLOTS_BYTES = CTX_ARR0 + 2 * CTX_ARR;
+constexpr int BAR_NONCE = BAR_ERR + 32;
+enum { A_KVQ = 0, A_SO = 1, A_CQ = 2, A_CO = 3, A_FC1 = 4, A_FC2 = 5 };
+
+struct PollCtx { unsigned* errw; int* s_bad; };
+
+// fetch `units` 16-byte units of one slot until all carry `tag` (long slots: spin on the last unit first — 1/14 of the traffic)
+template <int UMAX>
+__device__ __forceinline__ bool slot_fetch(rsrc_t srs, unsigned off, int units, unsigned tag, u32x4 (&un)[UMAX], const PollCtx& pc) {
+  const long long t0 = wall_clock64();
+  unsigned spins = 0;
+  for (;;) {
+    bool ok = true;
+    if (units > 4) ok = cld(srs, off + (unsigned)(units - 1) * 16u)[3] == tag;
+    if (ok) {
+#pragma unroll
+      for (int u = 0; u < UMAX; ++u)
+        if (u < units) un[u] = cld(srs, off + u * 16);
+#pragma unroll
+      for (int u = 0; u < UMAX; ++u)
+        if (u < units) ok = ok && un[u][3] == tag;
+      if (ok) return true;
+    }
+    if ((++spins & 63u) == 0 && (wall_clock64() - t0 > 200000000ll || __hip_atomic_load(pc.errw, __ATOMIC_RELAXED, AGENT) != 0)) {
+      __hip_atomic_store(pc.errw, 1u, __ATOMIC_RELAXED, AGENT);
+      *pc.s_bad = 1;
+      return false;
+    }
+  }
+}
+
+// consumer of a GEMV output [R][N]: thread i polls producer i's slot (ncw = 1 << lg columns x R rows) and scatters it into xs
+template <int UMAX>
+__device__ __forceinline__ void gather_cols(rsrc_t srs, unsigned arr, int nslots, int R, int lg, unsigned tag, bf16_t* xs, int K, int tid,
+                                            const PollCtx& pc) {
+  if (tid < nslots) {
+    const int ncw = 1 << lg, nval = R * ncw, units = (nval + 5) / 6;
+    u32x4 un[UMAX];
+    if (slot_fetch<UMAX>(srs, arr + (unsigned)tid * SLOT_STRIDE, units, tag, un, pc)) {
+#pragma unroll
+      for (int u = 0; u < UMAX; ++u)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const int v = 6 * u + 2 * j;
+          if (u < units && v < nval) *(unsigned*)(xs + (size_t)(v >> lg) * K + tid * ncw + (v & (ncw - 1))) = un[u][j];
+        }
+    }
+  }
+}
+// consumer of an attention output: thread i polls (row, head) pair i's slot (64 values) into xs[row][head * 64 ..]
+__device__ __forceinline__ void gather_ctx(rsrc_t srs, unsigned arr, int npair, int H, unsigned tag, bf16_t* xs, int K, int tid, const PollCtx& pc) {
+  if (tid < npair) {
+    u32x4 un[11];
+    if (slot_fetch<11>(srs, arr + (unsigned)tid * CTX_STRIDE, 11, tag, un, pc)) {
+      const int r = tid / H, h = tid - r * H;
+#pragma unroll
+      for (int u = 0; u < 11; ++u)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const int v = 6 * u + 2 * j;
+          if (v < 64) *(unsigned*)(xs + (size_t)r * K + h * 64 + v) = un[u][j];
+        }
+    }
+  }
+}
+// a (row r, head h) pair's 64-value pieces of a GEMV output: columns col0 .. col0+63 of row r -> dst[0..63] (npc = 64 >> lg slots)
+template <int UMAX>
+__device__ __forceinline__ void gather_piece(rsrc_t srs, unsigned arr, int col0, int R, int r, int lg, unsigned tag, bf16_t* dst, int j, const PollCtx& pc) {
+  const int ncw = 1 << lg, nval = R * ncw, units = (nval + 5) / 6;
+  u32x4 un[UMAX];
+  if (slot_fetch<UMAX>(srs, arr + (unsigned)((col0 >> lg) + j) * SLOT_STRIDE, units, tag, un, pc)) {
+#pragma unroll
+    for (int u = 0; u < UMAX; ++u)
+#pragma unroll
+      for (int jj = 0; jj < 3; ++jj) {
+        const int v = 6 * u + 2 * jj;
+        if (u < units && v < nval && (v >> lg) == r) *(unsigned*)(dst + j * ncw + (v & (ncw - 1))) = un[u][jj];
+      }
+  }
+}
+// producer: the workgroup's packed results (bf16 in LDS, value v = row * ncw + column) -> its slot, one unit per thread
+__device__ __forceinline__ void slot_put(rsrc_t srs, unsigned off, const unsigned short* pack, int nval, unsigned tag, int tid) {
+  if (tid < (nval + 5) / 6) {
+    const unsigned* pw = (const unsigned*)(pack + 6 * tid);
+    cst((u32x4){pw[0], pw[1], pw[2], tag}, srs, off + (unsigned)tid * 16u);
+  }
+}
+
+// LayerNorm in place: xs rows hold o, hres rows hold the residual h; xs <- LN(o + h) (bf16), hres <- the same rows
+// (add_ln_fwd_kernel's arithmetic: one wave per row, chunks lane / lane + 64, fp32 statistics; two rows per wave interleaved)
+__device__ __forceinline__ void ln_inplace(bf16_t* xs, bf16_t* hres, const float* lnp, int R, int K, float eps, int wave, int lane) {
+  const int nchunk = K >> 3;
+  float h[2][2][8];
+  float s[2] = {0.f, 0.f};
+  const bool on[2] = {wave < R, wave + NWAVE < R};
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = wave + NWAVE * rr, ch = lane + 64 * i;
+      if (on[rr] && ch < nchunk) {
+        float xv[8], rv[8];
+        unpack8(*(const u32x4*)(xs + (size_t)m * K + ch * 8), xv);
+        unpack8(*(const u32x4*)(hres + (size_t)m * K + ch * 8), rv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { xv[j] += rv[j]; h[rr][i][j] = xv[j]; s[rr] += xv[j]; }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) h[rr][i][j] = 0.f;
+      }
+    }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s[0] += __shfl_xor(s[0], o, 64); s[1] += __shfl_xor(s[1], o, 64); }
+  float mean[2], q[2] = {0.f, 0.f};
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) {
+    mean[rr] = s[rr] / K;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      if (lane + 64 * i < nchunk) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float dd = h[rr][i][j] - mean[rr]; q[rr] += dd * dd; }
+      }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { q[0] += __shfl_xor(q[0], o, 64); q[1] += __shfl_xor(q[1], o, 64); }
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) {
+    const float rstd = rsqrtf(q[rr] / K + eps);
+    const int m = wave + NWAVE * rr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ch = lane + 64 * i;
+      if (on[rr] && ch < nchunk) {
+        const f32x4 g0 = *(const f32x4*)(lnp + ch * 8), g1 = *(const f32x4*)(lnp + ch * 8 + 4);
+        const f32x4 b0 = *(const f32x4*)(lnp + 1024 + ch * 8), b1 = *(const f32x4*)(lnp + 1024 + ch * 8 + 4);
+        float y[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          y[j] = (h[rr][i][j] - mean[rr]) * rstd * g0[j] + b0[j];
+          y[4 + j] = (h[rr][i][4 + j] - mean[rr]) * rstd * g1[j] + b1[j];
+        }
+        const u32x4 packed = (u32x4){pack2bf(y[0], y[1]), pack2bf(y[2], y[3]), pack2bf(y[4], y[5]), pack2bf(y[6], y[7])};
+        *(u32x4*)(xs + (size_t)m * K + ch * 8) = packed;
+        *(u32x4*)(hres + (size_t)m * K + ch * 8) = packed;
+      }
+    }
+  }
+}
+
+#define TR3(K_) do { if (p.trace && wg == p.trace_wg && tid == 0) p.trace[phase * 8 + (K_)] = wall_clock64(); } while (0)
+#define SYNC_OR_QUIT() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); if (s_bad) return; } while (0)
+
+__global__ __launch_bounds__(NTHR) void decoder_step_slots_kernel(DecP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int G = gridDim.x, wg = blockIdx.x;
+  const int R = p.R, d = p.d, F = p.F, H = p.H;
+  bf16_t* xs = (bf16_t*)smem;                                   // [R][max(d, F)] bf16: the current phase's input rows
+  char* wbig = smem + p.xs_bytes + wave * WBIG;
+  char* wsml = smem + p.xs_bytes + NWAVE * WBIG + wave * WSMALL;
+  float* lnp = (float*)(smem + p.xs_bytes + NWAVE * (WBIG + WSMALL));
+  float* biasl = lnp + 2048;
+  bf16_t* hres = (bf16_t*)(biasl + 64);                         // [R][d] bf16: the residual stream
+  unsigned short* pack = (unsigned short*)(hres + (size_t)MR * 1024);   // [<= 8 rows][<= 16 columns] (+ unit padding)
+  bf16_t* qkvn = (bf16_t*)(pack + 160);                         // k | v | q of this position for one (row, head) pair: [3][64]
+  float* probs = (float*)(qkvn + 192);
+  __shared__ float part[NWAVE][32];
+  __shared__ int s_bad;
+  if (tid == 0) s_bad = 0;
+  const PollCtx pc = {p.bar + BAR_ERR, &s_bad};
+  const unsigned tag0 = __hip_atomic_load(p.bar + BAR_NONCE, __ATOMIC_RELAXED, AGENT) << 10;
+  const rsrc_t srs = mkrs(p.slots, SLOTS_BYTES);
+  const rsrc_t rs_cache = mkrs(p.cache, p.cache_bytes);
+  const unsigned row_b = (unsigned)p.Tstride * 2u;
+  const unsigned wb_dd = (unsigned)(d * d * 2), wb_fd = (unsigned)(F * d * 2);
+  const int c1 = wg * NWAVE + wave, c4 = c1 * 4;
+  const int npair = R * H, t_dd = d >> 2, t_3d = (3 * d) >> 4, t_f = F >> 4;    // producers of an N = d / 3d / F phase
+  int phase = 0;
+  {
+    const vacnic_decoder_layer l0 = p.layers[0];
+    w_issue<4>(wbig, mkrs(l0.w_kvq, 3 * wb_dd), 3 * d, d, c4, lane);
+    bias_issue(biasl, l0.b_kvq, 3 * d, wg * 16, 16, wave, lane);
+  }
+  // h <- h0 (written by the embedding kernel before this launch)
+  for (int c = tid; c < R * (d >> 3); c += NTHR) {
+    const u32x4 v = *(const u32x4*)(p.h0 + (size_t)c * 8);
+    *(u32x4*)(hres + (size_t)c * 8) = v;
+    *(u32x4*)(xs + (size_t)c * 8) = v;
+  }
+  for (int li = 0; li < p.L; ++li) {
+    const vacnic_decoder_layer ly = p.layers[li];
+    const unsigned lay_b = (unsigned)li * (unsigned)R * row_b;
+    const unsigned tg = tag0 + (unsigned)li * 8u;               // tag of this layer's phase X: tg + X + 1
+    // ---- P1: k|v|q.  k|v also go to the cache row of position t (plain stores: read by later launches only)
+    phase = li * 8;
+    if (li > 0) gather_cols<6>(srs, A_FC2 * SLOT_ARR, t_dd, R, 2, tg, xs, d, tid, pc);     // tag of (li - 1, P8) = tg
+    SYNC_OR_QUIT();
+    TR3(1);
+    if (li > 0) { ln_inplace(xs, hres, lnp, R, d, p.eps, wave, lane); __syncthreads(); }
+    if (c4 < 3 * d) {
+      int idx; bool owner;
+      float v = gemv_reduce<4>(wbig, xs, R, d, lane, idx, owner);
+      if (owner) {
+        const int m = idx >> 2, c = idx & 3, n = c4 + c;
+        v += biasl[wave * 4 + c];
+        const bf16_t b = f2bf(v);
+        pack[m * 16 + wave * 4 + c] = b;
+        if (m < R && n < 2 * d) p.cache[(size_t)li * R * p.Tstride + (size_t)m * p.Tstride + (size_t)p.t * 2 * d + n] = b;
+      }
+    }
+    __syncthreads();
+    TR3(3);
+    if (wg < t_3d) slot_put(srs, A_KVQ * SLOT_ARR + (unsigned)wg * SLOT_STRIDE, pack, R * 16, tg + 1, tid);
+    w_issue<1>(wsml, mkrs(ly.w_so, wb_dd), d, d, c1, lane); bias_issue(biasl, ly.b_so, d, wg * 4, 4, wave, lane);
+    // ---- P2: self-attention of (row, head) pair wg over cache rows 0..t-1 and the new row
+    phase = li * 8 + 1;
+    if (wg < npair) {
+      const int r = wg / H, h = wg - r * H;
+      if (tid < 12) {
+        const int which = tid >> 2;
+        gather_piece<22>(srs, A_KVQ * SLOT_ARR, which * d + h * 64, R, r, 4, tg + 1, qkvn + which * 64, tid & 3, pc);
+      }
+      SYNC_OR_QUIT();
+      TR3(1);
+      const unsigned rb = lay_b + (unsigned)r * row_b + (unsigned)h * 128u;
+      const AttnNew an = {qkvn + 128, qkvn, qkvn + 64, p.t};
+      float res[8];
+      attn_pair<0>(rs_cache, 0u, rs_cache, rb, rb + (unsigned)d * 2u, (unsigned)(2 * d) * 2u, p.t + 1, nullptr, p.scale, rs_cache, 0u, probs,
+                   wave, lane, an, res);
+      if (wave == 0 && lane < 8)
+        *(u32x4*)(pack + lane * 8) = (u32x4){pack2bf(res[0], res[1]), pack2bf(res[2], res[3]), pack2bf(res[4], res[5]), pack2bf(res[6], res[7])};
+      __syncthreads();
+      TR3(3);
+      slot_put(srs, CTX_ARR0 + (unsigned)wg * CTX_STRIDE, pack, 64, tg + 2, tid);
+    }
+    // ---- P3: self-attention output projection
+    phase = li * 8 + 2;
+    gather_ctx(srs, CTX_ARR0, npair, H, tg + 2, xs, d, tid, pc);
+    SYNC_OR_QUIT();
+    TR3(1);
+    if (c1 < d) {
+      int idx; bool owner;
+      float v = gemv_reduce<1>(wsml, xs, R, d, lane, idx, owner);
+      if (owner) pack[idx * 4 + wave] = f2bf(v + biasl[wave]);
+    }
+    __syncthreads();
+    TR3(3);
+    if (wg < t_dd) slot_put(srs, A_SO * SLOT_ARR + (unsigned)wg * SLOT_STRIDE, pack, R * 4, tg + 3, tid);
+    w_issue<1>(wsml, mkrs(ly.w_cq, wb_dd), d, d, c1, lane); bias_issue(biasl, ly.b_cq, d, wg * 4, 4, wave, lane);
+    ln_issue(lnp, ly.ln_self_g, ly.ln_self_b, d, wave, lane);
+    // ---- P4: post-LN of the self-attention block, cross-attention query
+    phase = li * 8 + 3;
+    gather_cols<6>(srs, A_SO * SLOT_ARR, t_dd, R, 2, tg + 3, xs, d, tid, pc);
+    SYNC_OR_QUIT();
+    TR3(1);
+    ln_inplace(xs, hres, lnp, R, d, p.eps, wave, lane);
+    __syncthreads();
+    if (c1 < d) {
+      int idx; bool owner;
+      float v = gemv_reduce<1>(wsml, xs, R, d, lane, idx, owner);
+      if (owner) pack[idx * 4 + wave] = f2bf(v + biasl[wave]);
+    }
+    __syncthreads();
+    TR3(3);
+    if (wg < t_dd) slot_put(srs, A_CQ * SLOT_ARR + (unsigned)wg * SLOT_STRIDE, pack, R * 4, tg + 4, tid);
+    w_issue<1>(wsml, mkrs(ly.w_co, wb_dd), d, d, c1, lane); bias_issue(biasl, ly.b_co, d, wg * 4, 4, wave, lane);
+    // ---- P5: cross-attention of pair wg over the encoder K/V
+    phase = li * 8 + 4;
+    if (wg < npair) {
+      const int r = wg / H, h = wg - r * H;
+      if (tid < 16) gather_piece<6>(srs, A_CQ * SLOT_ARR, h * 64, R, r, 2, tg + 4, qkvn + 128, tid, pc);
+      SYNC_OR_QUIT();
+      TR3(1);
+      const unsigned kv_rows = ly.cross_bs == 0 ? 1u : (unsigned)R;
+      const rsrc_t rs_kv = mkrs(ly.cross_kv, kv_rows * (unsigned)p.S * (unsigned)(2 * d) * 2u);
+      const unsigned kb = (unsigned)r * (unsigned)ly.cross_bs * 2u + (unsigned)h * 128u;
+      const AttnNew an = {qkvn + 128, nullptr, nullptr, -1};
+      float res[8];
+      attn_pair<0>(rs_kv, 0u, rs_kv, kb, kb + (unsigned)d * 2u, (unsigned)(2 * d) * 2u, p.S, p.enc_mask ? p.enc_mask + (size_t)r * p.S : nullptr,
+                   p.scale, rs_kv, 0u, probs, wave, lane, an, res);
+      if (wave == 0 && lane < 8)
+        *(u32x4*)(pack + lane * 8) = (u32x4){pack2bf(res[0], res[1]), pack2bf(res[2], res[3]), pack2bf(res[4], res[5]), pack2bf(res[6], res[7])};
+      __syncthreads();
+      TR3(3);
+      slot_put(srs, CTX_ARR0 + CTX_ARR + (unsigned)wg * CTX_STRIDE, pack, 64, tg + 5, tid);
+    }
+    // ---- P6: cross-attention output projection
+    phase = li * 8 + 5;
+    gather_ctx(srs, CTX_ARR0 + CTX_ARR, npair, H, tg + 5, xs, d, tid, pc);
+    SYNC_OR_QUIT();
+    TR3(1);
+    if (c1 < d) {
+      int idx; bool owner;
+      float v = gemv_reduce<1>(wsml, xs, R, d, lane, idx, owner);
+      if (owner) pack[idx * 4 + wave] = f2bf(v + biasl[wave]);
+    }
+    __syncthreads();
+    TR3(3);
+    if (wg < t_dd) slot_put(srs, A_CO * SLOT_ARR + (unsigned)wg * SLOT_STRIDE, pack, R * 4, tg + 6, tid);
+    w_issue<4>(wbig, mkrs(ly.w_fc1, wb_fd), F, d, c4, lane); bias_issue(biasl, ly.b_fc1, F, wg * 16, 16, wave, lane);
+    ln_issue(lnp, ly.ln_cross_g, ly.ln_cross_b, d, wave, lane);
+    // ---- P7: post-LN of the cross-attention block, fc1 + GELU
+    phase = li * 8 + 6;
+    gather_cols<6>(srs, A_CO * SLOT_ARR, t_dd, R, 2, tg + 6, xs, d, tid, pc);
+    SYNC_OR_QUIT();
+    TR3(1);
+    ln_inplace(xs, hres, lnp, R, d, p.eps, wave, lane);
+    __syncthreads();
+    if (c4 < F) {
+      int idx; bool owner;
+      float v = gemv_reduce<4>(wbig, xs, R, d, lane, idx, owner);
+      if (owner) pack[(idx >> 2) * 16 + wave * 4 + (idx & 3)] = f2bf(act_fwd(VACNIC_ACT_GELU, v + biasl[wave * 4 + (idx & 3)]));
+    }
+    __syncthreads();
+    TR3(3);
+    if (wg < t_f) slot_put(srs, A_FC1 * SLOT_ARR + (unsigned)wg * SLOT_STRIDE, pack, R * 16, tg + 7, tid);
+    w2_issue(wbig, mkrs(ly.w_fc2, wb_fd), d, F, wg * 4, wave, lane); bias_issue(biasl, ly.b_fc2, d, wg * 4, 4, wave, lane);
+    // ---- P8: fc2 (4 columns per workgroup, the waves split K and meet in LDS: gemm_skinny_kernel<8, 4, 4>)
+    phase = li * 8 + 7;
+    gather_cols<22>(srs, A_FC1 * SLOT_ARR, t_f, R, 4, tg + 7, xs, F, tid, pc);
+    SYNC_OR_QUIT();
+    TR3(1);
+    {
+      float acc[32];
+#pragma unroll
+      for (int i = 0; i < 32; ++i) acc[i] = 0.f;
+      const int nchunk = F >> 3;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ch = lane + 64 * wave + 256 * i;
+        if (ch < nchunk) {
+          float wv[4][8];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) unpack8(w_get(wbig, c * 2 + i, lane), wv[c]);
+#pragma unroll
+          for (int m = 0; m < MR; ++m) {
+            if (m < R) {
+              float xv[8];
+              unpack8(*(const u32x4*)(xs + (size_t)m * F + ch * 8), xv);
+#pragma unroll
+              for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[m * 4 + c] += xv[j] * wv[c][j];
+            }
+          }
+        }
+      }
+      int idx; bool owner;
+      float v = bfly32(acc, lane, idx, owner);
+      if (owner) part[wave][idx] = v;
+      __syncthreads();
+      if (wave == 0 && owner) {
+        v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWAVE; ++w) v += part[w][idx];
+        pack[idx] = f2bf(v + biasl[idx & 3]);                   // idx = row * 4 + column
+      }
+    }
+    __syncthreads();
+    TR3(3);
+    if (wg < t_dd) slot_put(srs, A_FC2 * SLOT_ARR + (unsigned)wg * SLOT_STRIDE, pack, R * 4, tg + 8, tid);
+    if (li + 1 < p.L) {
+      const vacnic_decoder_layer nx = p.layers[li + 1];
+      w_issue<4>(wbig, mkrs(nx.w_kvq, 3 * wb_dd), 3 * d, d, c4, lane); bias_issue(biasl, nx.b_kvq, 3 * d, wg * 16, 16, wave, lane);
+      ln_issue(lnp, ly.ln_final_g, ly.ln_final_b, d, wave, lane);
+    }
+  }
+  // workgroup 0 hands the last layer's (block output, residual) pair to the LM-head kernel and bumps the launch nonce
+  if (wg == 0) {
+    phase = p.L * 8;
+    gather_cols<6>(srs, A_FC2 * SLOT_ARR, t_dd, R, 2, tag0 + (unsigned)(p.L - 1) * 8u + 8u, xs, d, tid, pc);
+    SYNC_OR_QUIT();
+    bf16_t* hout = (p.L & 1) ? p.hb1 : p.hb0;
+    for (int c = tid; c < R * (d >> 3); c += NTHR) {
+      *(u32x4*)(p.o + (size_t)c * 8) = *(const u32x4*)(xs + (size_t)c * 8);
+      *(u32x4*)(hout + (size_t)c * 8) = *(const u32x4*)(hres + (size_t)c * 8);
+    }
+    if (tid == 0) __hip_atomic_store(p.bar + BAR_NONCE, (tag0 >> 10) + 1u, __ATOMIC_RELAXED, AGENT);
+  }
+}
+
 }  // namespace
 
-extern "C" int64_t vacnic_decoder_step_sync_bytes(void) { return (int64_t)(BAR_ERR + 32) * 4; }
+extern "C" int64_t vacnic_decoder_step_sync_bytes(void) { return (int64_t)(BAR_NONCE + 32) * 4; }
+extern "C" int64_t vacnic_decoder_step_slots_bytes(void) { return (int64_t)SLOTS_BYTES; }
 
 extern "C" int vacnic_decoder_step(const vacnic_decoder_step_args* a, void* stream) {
   VCHECK(a && a->layers && a->cache && a->h0 && a->hbuf[0] && a->hbuf[1] && a->obuf && a->ctx && a->qbuf && a->fbuf && a->sync,
@@ -770,19 +1210,34 @@ extern "C" int vacnic_decoder_step(const vacnic_decoder_step_args* a, void* stre
   p.xs_bytes = (unsigned)(a->R * kmax * 2);
   p.eps = a->eps; p.scale = a->scale;
   p.trace = (unsigned long long*)a->trace; p.trace_wg = (int)a->trace_wg;
+  p.slots = (char*)a->slots;
   const int64_t tkmax = a->S > a->t + 1 ? a->S : a->t + 1;
-  const size_t lds = (size_t)p.xs_bytes + (size_t)NWAVE * (WBIG + WSMALL) + (size_t)(2048 + 64) * 4 + (size_t)(tkmax + NWAVE * 64 + 8) * 4;
+  const bool use_slots = a->slots != nullptr;
+  size_t lds = (size_t)p.xs_bytes + (size_t)NWAVE * (WBIG + WSMALL) + (size_t)(2048 + 64) * 4 + (size_t)(tkmax + NWAVE * 64 + 8) * 4;
+  if (use_slots) lds += (size_t)MR * 1024 * 2 + 160 * 2 + 192 * 2;
   VCHECK(lds <= 150 * 1024, VACNIC_UNSUPPORTED, "decoder_step: LDS budget");
-  static size_t lds_set = 0;
-  if (lds > 65536 - 1024 && lds > lds_set) {
-    if (hipFuncSetAttribute((const void*)decoder_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(150 * 1024)) != hipSuccess) {
+  static bool lds_set[2] = {false, false};
+  if (lds > 65536 - 1024 && !lds_set[use_slots]) {
+    const void* fn = use_slots ? (const void*)decoder_step_slots_kernel : (const void*)decoder_step_kernel;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(150 * 1024)) != hipSuccess) {
       vacnic_set_error("decoder_step: cannot raise the dynamic LDS limit");
       return VACNIC_HIP_ERROR;
     }
-    lds_set = 150 * 1024;
+    lds_set[use_slots] = true;
   }
-  const int G = n_cu < 256 ? n_cu : 256;
-  hipLaunchKernelGGL(decoder_step_kernel, dim3(G), dim3(NTHR), lds, (hipStream_t)stream, p);
+  if (use_slots) {
+    // one workgroup per 4 columns of a d-wide projection / 16 columns of the FFN: every launched workgroup produces in the last
+    // layer's fc1 or fc2, both consumed by workgroup 0 before it bumps the launch nonce
+    VCHECK((a->d & 15) == 0 && (a->F & 15) == 0 && a->L <= 120, VACNIC_UNSUPPORTED, "decoder_step (slots): d, F multiples of 16, L <= 120");
+    const int64_t G = a->d / 4 > a->F / 16 ? a->d / 4 : a->F / 16;
+    VCHECK(G <= 256 && G <= n_cu && a->R * a->H <= 128 && a->R * a->H <= G, VACNIC_UNSUPPORTED,
+           "decoder_step (slots): needs max(d / 4, ffn / 16) <= min(256, CUs) co-resident workgroups");
+    VCHECK(aligned16(a->slots), VACNIC_MISALIGNED, "decoder_step: slots must be 16-byte aligned");
+    hipLaunchKernelGGL(decoder_step_slots_kernel, dim3((unsigned)G), dim3(NTHR), lds, (hipStream_t)stream, p);
+  } else {
+    const int G = n_cu < 256 ? n_cu : 256;
+    hipLaunchKernelGGL(decoder_step_kernel, dim3(G), dim3(NTHR), lds, (hipStream_t)stream, p);
+  }
   VLAUNCH_CHECK();
   return VACNIC_OK;
 }

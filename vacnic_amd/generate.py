@@ -24,6 +24,47 @@ from . import _lib, kernels as K
 BF16 = torch.bfloat16
 
 
+class GraphedCall:
+    """fn(*tensors) -> tensor(s), captured as a hipGraph per input signature (shapes + dtypes) and replayed: at batch 1 the
+    encoder / ViT of a caption are ~600 launches of a few microseconds of work each, i.e. bound by the Python launch path
+    (5.5 + 2.5 ms per caption eagerly).  First sighting of a signature runs eagerly (warms kernels and lazy buffers), the second
+    captures, later ones copy the inputs into the graph's static buffers and replay.  The outputs live in the graph's pool and
+    are overwritten by the next replay — callers consume them before calling again.  A body that cannot be captured (host
+    synchronisation inside) stays eager for that signature."""
+
+    def __init__(self, fn, max_entries=8):
+        self.fn, self.cache, self.max_entries = fn, {}, max_entries
+
+    def __call__(self, *args):
+        key = tuple((tuple(a.shape), a.dtype) if a is not None else None for a in args)
+        ent = self.cache.get(key)
+        if ent is None:
+            if len(self.cache) >= self.max_entries:
+                self.cache.pop(next(iter(self.cache)))
+            self.cache[key] = "seen"
+            return self.fn(*args)
+        if ent == "eager":
+            return self.fn(*args)
+        if ent == "seen":
+            static = [a.clone() if a is not None else None for a in args]
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            try:
+                with torch.cuda.graph(g):
+                    out = self.fn(*static)
+            except RuntimeError:
+                torch.cuda.synchronize()
+                self.cache[key] = "eager"
+                return self.fn(*args)
+            ent = self.cache[key] = (g, static, out)
+        g, static, out = ent
+        for st, a in zip(static, args):
+            if st is not None:
+                st.copy_(a, non_blocking=True)
+        g.replay()
+        return out
+
+
 class _BeamHyps:
     """n-best list of finished hypotheses, scored sum_logprobs / len**length_penalty (len counts the decoder start token,
     not the closing EOS) — transformers==4.18 BeamHypotheses."""
@@ -90,6 +131,13 @@ class CachedDecoder:
         self.trace, self.trace_wg = None, 0       # tools/decstep_trace.py: per-phase time stamps of one workgroup
         if self.step_kernel:
             self.sync = torch.zeros(int(_lib.lib.vacnic_decoder_step_sync_bytes()) // 4, device=dev, dtype=torch.int32)
+            # tagged-slot exchange (no grid barriers) when the workgroup count fits the GPU; VACNIC_DECODE_BARRIER=1: barrier variant
+            cus = torch.cuda.get_device_properties(dev).multi_processor_count
+            G = max(d // 4, F // 16)
+            self.slots = None
+            if (os.environ.get("VACNIC_DECODE_BARRIER", "0") != "1" and d % 16 == 0 and F % 16 == 0 and G <= min(256, cus)
+                    and rows * self.H <= min(128, G) and self.L <= 120):
+                self.slots = torch.zeros(int(_lib.lib.vacnic_decoder_step_slots_bytes()), device=dev, dtype=torch.uint8)
             self.hbuf = [torch.zeros((rows, d), device=dev, dtype=BF16) for _ in range(2)]
             self.obuf, self.ctxb, self.qbuf = (torch.zeros((rows, d), device=dev, dtype=BF16) for _ in range(3))
             self.fbuf = torch.zeros((rows, F), device=dev, dtype=BF16)
@@ -144,14 +192,14 @@ class CachedDecoder:
         _lib.call_struct("vacnic_decoder_step", stream=K._stream(), layers=self._layer_table().data_ptr(), cache=self.cache_at(t).data_ptr(),
                          h0=h.data_ptr(), hbuf0=self.hbuf[0].data_ptr(), hbuf1=self.hbuf[1].data_ptr(), obuf=self.obuf.data_ptr(),
                          ctx=self.ctxb.data_ptr(), qbuf=self.qbuf.data_ptr(), fbuf=self.fbuf.data_ptr(), enc_mask=self.enc_mask.data_ptr(),
-                         sync=self.sync.data_ptr(), L=self.L, R=self.rows, d=self.d, H=self.H, F=self.F, S=self.S, t=t, Tmax=self.Tmax,
+                         sync=self.sync.data_ptr(), slots=self.slots.data_ptr() if self.slots is not None else None, L=self.L, R=self.rows, d=self.d, H=self.H, F=self.F, S=self.S, t=t, Tmax=self.Tmax,
                          eps=lay.final_layer_norm.eps, scale=0.125, trace=self.trace.data_ptr() if self.trace is not None else None,
                          trace_wg=self.trace_wg)
         return self.obuf, self.hbuf[self.L & 1]
 
     def check_step_kernel(self):
         """after the results were read back: did a grid barrier of the step kernel time out?"""
-        if self.step_kernel and int(self.sync[-32].item()) != 0:
+        if self.step_kernel and int(self.sync[-64].item()) != 0:
             self.sync.zero_()
             raise RuntimeError("vacnic_decoder_step: a grid barrier timed out (workgroups not co-resident?); results are invalid")
 
@@ -379,9 +427,16 @@ def generate(model, input_ids=None, attention_mask=None, num_beams=1, max_length
     nb = num_beams
     R = B * nb
     mask_u8 = attention_mask.to(torch.uint8) if attention_mask.dtype != torch.uint8 else attention_mask
-    enc = model.model.encoder(input_ids=input_ids, attention_mask=mask_u8, image_features=image_features, name_ids=name_ids,
-                              name_mask=name_mask, face_features=face_features, face_mask=face_mask, add_ner_ffn=add_ner_ffn)
-    enc_h = enc["last_hidden_state"]
+    def run_encoder(ids, m8, img, nids, nmask, faces, fmask):
+        return model.model.encoder(input_ids=ids, attention_mask=m8, image_features=img, name_ids=nids, name_mask=nmask,
+                                   face_features=faces, face_mask=fmask, add_ner_ffn=add_ner_ffn)["last_hidden_state"]
+    if use_graphs:
+        ge = model.__dict__.setdefault("_graphed_encoders", {})
+        if add_ner_ffn not in ge:
+            ge[add_ner_ffn] = GraphedCall(run_encoder)
+        enc_h = ge[add_ner_ffn](input_ids, mask_u8, image_features, name_ids, name_mask, face_features, face_mask)
+    else:
+        enc_h = run_encoder(input_ids, mask_u8, image_features, name_ids, name_mask, face_features, face_mask)
     S, d = enc_h.shape[1], enc_h.shape[2]
     device_beams = bool(device_beams) and nb <= 16 and 2 * nb * nb <= 128 and max_length <= 512
     key = (R, S, max_length, nb, no_repeat_ngram_size, min_length, forced_eos_token_id, forced_bos_token_id,

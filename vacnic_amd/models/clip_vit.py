@@ -125,8 +125,20 @@ class CLIPVisualOnly(nn.Module):
 def extract_clip_img_feat(clip_model, x):
     """Drop-in for TRAIN:220-240: returns (ln_post(patch tokens), ln_post(cls)) as fp32 tensors, no grad."""
     with torch.no_grad():
-        vis = clip_model.eval().visual
+        if clip_model.training:
+            clip_model.eval()
+        vis = clip_model.visual
         if vis.arena is None:
             raise RuntimeError("call clip_model.finalize(device) first")
         patches, cls = vis.features(x)
         return K.cast_bf16_f32(patches.contiguous()), K.cast_bf16_f32(cls.contiguous())
+
+
+def graphed_clip_img_feat(clip_model):
+    """extract_clip_img_feat as a hipGraph per image-batch shape (caption generation at batch 1: the ViT is ~250 launches of a few
+    microseconds each); returns a callable x -> (patch tokens, cls).  The outputs are overwritten by the next call."""
+    from ..generate import GraphedCall
+    g = clip_model.__dict__.get("_graphed_feat")
+    if g is None:
+        g = clip_model.__dict__["_graphed_feat"] = GraphedCall(lambda x: extract_clip_img_feat(clip_model, x))
+    return g
