@@ -345,9 +345,11 @@ int vacnic_beam_step(const vacnic_beam_state* st, const float* top_val, const in
  *            elements between rows (0: all rows share one source — the beams of one caption).
  *   cache    bf16 [L][R][Tmax + 1][2d]: k|v of position t are written at [l][r][t][0:2d], q is parked at [l][r][t + 1][0:d].
  *   h0       bf16 [R][d]: embedding LayerNorm output of the new token (vacnic_embed_ln_fwd).
- *   hbuf/obuf/ctx/qbuf ([R][d]) and fbuf ([R][F]): scratch.  On return the last layer's un-normalised block output is obuf and
- *            its residual is hbuf[L & 1]; final_layer_norm of the last layer is left to the consumer (vacnic_gemv_ln_bf16 with
- *            the LM head).
+ *   hbuf/obuf/ctx/qbuf ([R][d]) and fbuf ([R][F]): scratch.  Grid-barrier variant: on return the last layer's un-normalised
+ *            block output is obuf and its residual is hbuf[L & 1]; final_layer_norm of the last layer is left to the consumer
+ *            (vacnic_gemv_ln_bf16 with the LM head).  Slot variant: obuf holds the decoder's final hidden rows (final_layer_norm
+ *            applied), ready for the LM-head GEMM; its projections run on the matrix cores (fp32 sums associate differently
+ *            from the VALU kernels: parity to bf16 tolerance, not to the bit).
  *   sync     vacnic_decoder_step_sync_bytes() bytes, zeroed ONCE by the caller; word [sync_bytes / 4 - 64] is an error flag the
  *            kernel raises (and leaves) if a wait times out — check it when the results are read back.
  *   slots    vacnic_decoder_step_slots_bytes() bytes, zeroed ONCE by the caller: the phases hand their results over through

@@ -10,7 +10,7 @@ from vacnic_amd.training import build_models
 cfg, vcfg = bart_large_vit_l14()
 model, _, _ = build_models(cfg, vcfg, device="cuda", seed=42, init="device", with_guide=False)
 model.eval()
-R, nb, S, Tmax = 5, 5, 512 + 20, 50
+R, nb, S, Tmax = 5, 5, 512, 50
 g = torch.Generator().manual_seed(0)
 enc_h = (torch.randn(1, S, cfg.d_model, generator=g) * 0.5).bfloat16().cuda()
 mask = torch.ones(1, S, dtype=torch.uint8).cuda()

@@ -797,14 +797,14 @@ enum { A_KVQ = 0, A_SO = 1, A_CQ = 2, A_CO = 3, A_FC1 = 4, A_FC2 = 5 };
 
 struct PollCtx { unsigned* errw; int* s_bad; };
 
-// fetch `units` 16-byte units of one slot until all carry `tag` (long slots: spin on the last unit first — 1/14 of the traffic)
+// fetch `units` 16-byte units of one slot until all carry `tag` (slots of > 11 units: spin on the last unit first — 1/14 of the traffic)
 template <int UMAX>
 __device__ __forceinline__ bool slot_fetch(rsrc_t srs, unsigned off, int units, unsigned tag, u32x4 (&un)[UMAX], const PollCtx& pc) {
   const long long t0 = wall_clock64();
   unsigned spins = 0;
   for (;;) {
     bool ok = true;
-    if (units > 4) ok = cld(srs, off + (unsigned)(units - 1) * 16u)[3] == tag;
+    if (units > 11) ok = cld(srs, off + (unsigned)(units - 1) * 16u)[3] == tag;
     if (ok) {
 #pragma unroll
       for (int u = 0; u < UMAX; ++u)
@@ -879,9 +879,77 @@ __device__ __forceinline__ void slot_put(rsrc_t srs, unsigned off, const unsigne
   }
 }
 
+// ---- slot variant: MFMA projections ------------------------------------------------------------------------------------
+// A workgroup's output tile is NC = 16 (k|v|q, fc1) or 4 (d-wide projections, fc2) weight rows x all activation rows; one
+// v_mfma_f32_16x16x32_bf16 multiplies 16 weight rows by 16 activation rows (R valid, the rest zero) over 32 k, the 4 waves split
+// K and meet in LDS.  ~0.3 us instead of ~500-1000 VALU instructions per wave (1.5-3 us with one wave per SIMD).  The weight
+// tile arrives by LDS-DMA already in fragment order:
+//   16-row tile: piece s of wave w = MFMA step kk = w * per + s: lane l <- W[n0 + (l & 15)][8 * (4 kk + (l >> 4)) .. + 8]
+//   4-row tile:  piece s of wave w covers 4 steps: lane l <- W[n0 + (l & 3)][8 * (16 (w * per4 + s) + (l >> 2)) .. + 8]
+// Sums differ from the VALU path in the last fp32 bits (different association).
+__device__ __forceinline__ float wave_sum_fast(float v) {
+  // quad xor 1, xor 2, mirror within 8, mirror within 16 (DPP: ~8 cycles each instead of a ~100-cycle ds_bpermute), then the 4 rows
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
+  const int iv = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16)) +
+         __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+}
+__device__ __forceinline__ int steps_per_wave(int K) { return ((K + 31) / 32 + NWAVE - 1) / NWAVE; }
+
+__device__ __forceinline__ void w16_issue(char* wl, rsrc_t wrs, int N, int K, int n0, int wave, int lane) {
+  const int nchunk = K >> 3, per = steps_per_wave(K);
+  const int col = n0 + (lane & 15);
+  for (int s_ = 0; s_ < per; ++s_) {
+    const int ch = 4 * (wave * per + s_) + (lane >> 4);
+    wdma(wrs, wl + s_ * 1024, (col < N && ch < nchunk) ? (unsigned)(col * K + ch * 8) * 2u : OOB);
+  }
+}
+__device__ __forceinline__ void w4_issue(char* wl, rsrc_t wrs, int N, int K, int n0, int wave, int lane) {
+  const int nchunk = K >> 3, per4 = (steps_per_wave(K) + 3) / 4;
+  const int col = n0 + (lane & 3);
+  for (int s_ = 0; s_ < per4; ++s_) {
+    const int ch = 16 * (wave * per4 + s_) + (lane >> 2);
+    wdma(wrs, wl + s_ * 1024, (col < N && ch < nchunk) ? (unsigned)(col * K + ch * 8) * 2u : OOB);
+  }
+}
+// this wave's share of D[weight row][activation row]; xs rows have stride Kp (elements), rows >= R count as zero
+template <bool NC16>
+__device__ __forceinline__ f32x4 mfma_share(const char* wl, const bf16_t* xs, int Kp, int R, int K, int wave, int lane) {
+  const int nchunk = K >> 3;
+  const int per = NC16 ? steps_per_wave(K) : 4 * ((steps_per_wave(K) + 3) / 4);
+  const int m = lane & 15, g = lane >> 4;
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int s_ = 0; s_ < per; ++s_) {
+    const int kk = wave * per + s_, ch = 4 * kk + g;
+    u32x4 xr = (u32x4){0, 0, 0, 0}, wr = (u32x4){0, 0, 0, 0};
+    if (m < R && ch < nchunk) xr = *(const u32x4*)(xs + (size_t)m * Kp + ch * 8);
+    if (NC16) wr = *(const u32x4*)(wl + s_ * 1024 + lane * 16);
+    else if (m < 4) wr = *(const u32x4*)(wl + (s_ >> 2) * 1024 + (m + 4 * (4 * (s_ & 3) + g)) * 16);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wr), __builtin_bit_cast(bf16x8, xr), acc, 0, 0, 0);
+  }
+  return acc;
+}
+// the 4 waves' shares meet in LDS; thread e = lane * 4 + j of the fragment layout owns (weight row n = 4 (e >> 6) + (e & 3),
+// activation row m = (e >> 2) & 15): bias, activation, bf16 into pack[m * ncw + n].  Ends with a workgroup barrier.
+template <bool NC16>
+__device__ __forceinline__ void mfma_finish(f32x4 acc, float* red, const float* biasl, int act, unsigned short* pack, int R, int tid, int wave, int lane) {
+  *(f32x4*)(red + wave * 256 + lane * 4) = acc;
+  __syncthreads();
+  const int n = 4 * (tid >> 6) + (tid & 3), m = (tid >> 2) & 15;
+  constexpr int NC = NC16 ? 16 : 4;
+  if (m < R && n < NC) {
+    float v = red[tid] + red[256 + tid] + red[512 + tid] + red[768 + tid] + biasl[n];
+    pack[m * NC + n] = f2bf(act_fwd(act, v));
+  }
+  __syncthreads();
+}
+
 // LayerNorm in place: xs rows hold o, hres rows hold the residual h; xs <- LN(o + h) (bf16), hres <- the same rows
 // (add_ln_fwd_kernel's arithmetic: one wave per row, chunks lane / lane + 64, fp32 statistics; two rows per wave interleaved)
-__device__ __forceinline__ void ln_inplace(bf16_t* xs, bf16_t* hres, const float* lnp, int R, int K, float eps, int wave, int lane) {
+__device__ __forceinline__ void ln_inplace(bf16_t* xs, int Kp, bf16_t* hres, const float* lnp, int R, int K, float eps, int wave, int lane) {
   const int nchunk = K >> 3;
   float h[2][2][8];
   float s[2] = {0.f, 0.f};
@@ -893,7 +961,7 @@ __device__ __forceinline__ void ln_inplace(bf16_t* xs, bf16_t* hres, const float
       const int m = wave + NWAVE * rr, ch = lane + 64 * i;
       if (on[rr] && ch < nchunk) {
         float xv[8], rv[8];
-        unpack8(*(const u32x4*)(xs + (size_t)m * K + ch * 8), xv);
+        unpack8(*(const u32x4*)(xs + (size_t)m * Kp + ch * 8), xv);
         unpack8(*(const u32x4*)(hres + (size_t)m * K + ch * 8), rv);
 #pragma unroll
         for (int j = 0; j < 8; ++j) { xv[j] += rv[j]; h[rr][i][j] = xv[j]; s[rr] += xv[j]; }
@@ -902,8 +970,7 @@ __device__ __forceinline__ void ln_inplace(bf16_t* xs, bf16_t* hres, const float
         for (int j = 0; j < 8; ++j) h[rr][i][j] = 0.f;
       }
     }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { s[0] += __shfl_xor(s[0], o, 64); s[1] += __shfl_xor(s[1], o, 64); }
+  s[0] = wave_sum_fast(s[0]); s[1] = wave_sum_fast(s[1]);
   float mean[2], q[2] = {0.f, 0.f};
 #pragma unroll
   for (int rr = 0; rr < 2; ++rr) {
@@ -915,8 +982,7 @@ __device__ __forceinline__ void ln_inplace(bf16_t* xs, bf16_t* hres, const float
         for (int j = 0; j < 8; ++j) { const float dd = h[rr][i][j] - mean[rr]; q[rr] += dd * dd; }
       }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { q[0] += __shfl_xor(q[0], o, 64); q[1] += __shfl_xor(q[1], o, 64); }
+  q[0] = wave_sum_fast(q[0]); q[1] = wave_sum_fast(q[1]);
 #pragma unroll
   for (int rr = 0; rr < 2; ++rr) {
     const float rstd = rsqrtf(q[rr] / K + eps);
@@ -934,12 +1000,13 @@ __device__ __forceinline__ void ln_inplace(bf16_t* xs, bf16_t* hres, const float
           y[4 + j] = (h[rr][i][4 + j] - mean[rr]) * rstd * g1[j] + b1[j];
         }
         const u32x4 packed = (u32x4){pack2bf(y[0], y[1]), pack2bf(y[2], y[3]), pack2bf(y[4], y[5]), pack2bf(y[6], y[7])};
-        *(u32x4*)(xs + (size_t)m * K + ch * 8) = packed;
+        *(u32x4*)(xs + (size_t)m * Kp + ch * 8) = packed;
         *(u32x4*)(hres + (size_t)m * K + ch * 8) = packed;
       }
     }
   }
 }
+
 
 #define TR3(K_) do { if (p.trace && wg == p.trace_wg && tid == 0) p.trace[phase * 8 + (K_)] = wall_clock64(); } while (0)
 #define SYNC_OR_QUIT() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); if (s_bad) return; } while (0)
@@ -947,9 +1014,10 @@ __device__ __forceinline__ void ln_inplace(bf16_t* xs, bf16_t* hres, const float
 __global__ __launch_bounds__(NTHR) void decoder_step_slots_kernel(DecP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int G = gridDim.x, wg = blockIdx.x;
+  const int wg = blockIdx.x;
   const int R = p.R, d = p.d, F = p.F, H = p.H;
-  bf16_t* xs = (bf16_t*)smem;                                   // [R][max(d, F)] bf16: the current phase's input rows
+  const int Kd = d + 8, Kf = F + 8;                             // xs row strides (elements): +16 bytes spreads the rows over the LDS banks
+  bf16_t* xs = (bf16_t*)smem;                                   // [R][max(d, F) + 8] bf16: the current phase's input rows
   char* wbig = smem + p.xs_bytes + wave * WBIG;
   char* wsml = smem + p.xs_bytes + NWAVE * WBIG + wave * WSMALL;
   float* lnp = (float*)(smem + p.xs_bytes + NWAVE * (WBIG + WSMALL));
@@ -957,8 +1025,8 @@ __global__ __launch_bounds__(NTHR) void decoder_step_slots_kernel(DecP p) {
   bf16_t* hres = (bf16_t*)(biasl + 64);                         // [R][d] bf16: the residual stream
   unsigned short* pack = (unsigned short*)(hres + (size_t)MR * 1024);   // [<= 8 rows][<= 16 columns] (+ unit padding)
   bf16_t* qkvn = (bf16_t*)(pack + 160);                         // k | v | q of this position for one (row, head) pair: [3][64]
-  float* probs = (float*)(qkvn + 192);
-  __shared__ float part[NWAVE][32];
+  float* red = (float*)(qkvn + 192);                            // [4 waves][256]: partial MFMA tiles
+  float* probs = red + 1024;
   __shared__ int s_bad;
   if (tid == 0) s_bad = 0;
   const PollCtx pc = {p.bar + BAR_ERR, &s_bad};
@@ -967,19 +1035,19 @@ __global__ __launch_bounds__(NTHR) void decoder_step_slots_kernel(DecP p) {
   const rsrc_t rs_cache = mkrs(p.cache, p.cache_bytes);
   const unsigned row_b = (unsigned)p.Tstride * 2u;
   const unsigned wb_dd = (unsigned)(d * d * 2), wb_fd = (unsigned)(F * d * 2);
-  const int c1 = wg * NWAVE + wave, c4 = c1 * 4;
   const int npair = R * H, t_dd = d >> 2, t_3d = (3 * d) >> 4, t_f = F >> 4;    // producers of an N = d / 3d / F phase
   int phase = 0;
   {
     const vacnic_decoder_layer l0 = p.layers[0];
-    w_issue<4>(wbig, mkrs(l0.w_kvq, 3 * wb_dd), 3 * d, d, c4, lane);
+    w16_issue(wbig, mkrs(l0.w_kvq, 3 * wb_dd), 3 * d, d, wg * 16, wave, lane);
     bias_issue(biasl, l0.b_kvq, 3 * d, wg * 16, 16, wave, lane);
   }
   // h <- h0 (written by the embedding kernel before this launch)
   for (int c = tid; c < R * (d >> 3); c += NTHR) {
+    const int m = c / (d >> 3), ch = c - m * (d >> 3);
     const u32x4 v = *(const u32x4*)(p.h0 + (size_t)c * 8);
     *(u32x4*)(hres + (size_t)c * 8) = v;
-    *(u32x4*)(xs + (size_t)c * 8) = v;
+    *(u32x4*)(xs + (size_t)m * Kd + ch * 8) = v;
   }
   for (int li = 0; li < p.L; ++li) {
     const vacnic_decoder_layer ly = p.layers[li];
@@ -987,25 +1055,18 @@ __global__ __launch_bounds__(NTHR) void decoder_step_slots_kernel(DecP p) {
     const unsigned tg = tag0 + (unsigned)li * 8u;               // tag of this layer's phase X: tg + X + 1
     // ---- P1: k|v|q.  k|v also go to the cache row of position t (plain stores: read by later launches only)
     phase = li * 8;
-    if (li > 0) gather_cols<6>(srs, A_FC2 * SLOT_ARR, t_dd, R, 2, tg, xs, d, tid, pc);     // tag of (li - 1, P8) = tg
+    if (li > 0) gather_cols<6>(srs, A_FC2 * SLOT_ARR, t_dd, R, 2, tg, xs, Kd, tid, pc);     // tag of (li - 1, P8) = tg
     SYNC_OR_QUIT();
     TR3(1);
-    if (li > 0) { ln_inplace(xs, hres, lnp, R, d, p.eps, wave, lane); __syncthreads(); }
-    if (c4 < 3 * d) {
-      int idx; bool owner;
-      float v = gemv_reduce<4>(wbig, xs, R, d, lane, idx, owner);
-      if (owner) {
-        const int m = idx >> 2, c = idx & 3, n = c4 + c;
-        v += biasl[wave * 4 + c];
-        const bf16_t b = f2bf(v);
-        pack[m * 16 + wave * 4 + c] = b;
-        if (m < R && n < 2 * d) p.cache[(size_t)li * R * p.Tstride + (size_t)m * p.Tstride + (size_t)p.t * 2 * d + n] = b;
-      }
-    }
-    __syncthreads();
+    if (li > 0) { ln_inplace(xs, Kd, hres, lnp, R, d, p.eps, wave, lane); __syncthreads(); }
+    mfma_finish<true>(mfma_share<true>(wbig, xs, Kd, R, d, wave, lane), red, biasl, VACNIC_ACT_NONE, pack, R, tid, wave, lane);
     TR3(3);
-    if (wg < t_3d) slot_put(srs, A_KVQ * SLOT_ARR + (unsigned)wg * SLOT_STRIDE, pack, R * 16, tg + 1, tid);
-    w_issue<1>(wsml, mkrs(ly.w_so, wb_dd), d, d, c1, lane); bias_issue(biasl, ly.b_so, d, wg * 4, 4, wave, lane);
+    if (wg < t_3d) {
+      slot_put(srs, A_KVQ * SLOT_ARR + (unsigned)wg * SLOT_STRIDE, pack, R * 16, tg + 1, tid);
+      const int m = tid >> 4, n = wg * 16 + (tid & 15);
+      if (m < R && n < 2 * d) p.cache[(size_t)li * R * p.Tstride + (size_t)m * p.Tstride + (size_t)p.t * 2 * d + n] = pack[m * 16 + (tid & 15)];
+    }
+    w4_issue(wsml, mkrs(ly.w_so, wb_dd), d, d, wg * 4, wave, lane); bias_issue(biasl, ly.b_so, d, wg * 4, 4, wave, lane);
     // ---- P2: self-attention of (row, head) pair wg over cache rows 0..t-1 and the new row
     phase = li * 8 + 1;
     if (wg < npair) {
@@ -1029,35 +1090,25 @@ __global__ __launch_bounds__(NTHR) void decoder_step_slots_kernel(DecP p) {
     }
     // ---- P3: self-attention output projection
     phase = li * 8 + 2;
-    gather_ctx(srs, CTX_ARR0, npair, H, tg + 2, xs, d, tid, pc);
+    gather_ctx(srs, CTX_ARR0, npair, H, tg + 2, xs, Kd, tid, pc);
     SYNC_OR_QUIT();
     TR3(1);
-    if (c1 < d) {
-      int idx; bool owner;
-      float v = gemv_reduce<1>(wsml, xs, R, d, lane, idx, owner);
-      if (owner) pack[idx * 4 + wave] = f2bf(v + biasl[wave]);
-    }
-    __syncthreads();
+    mfma_finish<false>(mfma_share<false>(wsml, xs, Kd, R, d, wave, lane), red, biasl, VACNIC_ACT_NONE, pack, R, tid, wave, lane);
     TR3(3);
     if (wg < t_dd) slot_put(srs, A_SO * SLOT_ARR + (unsigned)wg * SLOT_STRIDE, pack, R * 4, tg + 3, tid);
-    w_issue<1>(wsml, mkrs(ly.w_cq, wb_dd), d, d, c1, lane); bias_issue(biasl, ly.b_cq, d, wg * 4, 4, wave, lane);
+    w4_issue(wsml, mkrs(ly.w_cq, wb_dd), d, d, wg * 4, wave, lane); bias_issue(biasl, ly.b_cq, d, wg * 4, 4, wave, lane);
     ln_issue(lnp, ly.ln_self_g, ly.ln_self_b, d, wave, lane);
     // ---- P4: post-LN of the self-attention block, cross-attention query
     phase = li * 8 + 3;
-    gather_cols<6>(srs, A_SO * SLOT_ARR, t_dd, R, 2, tg + 3, xs, d, tid, pc);
+    gather_cols<6>(srs, A_SO * SLOT_ARR, t_dd, R, 2, tg + 3, xs, Kd, tid, pc);
     SYNC_OR_QUIT();
     TR3(1);
-    ln_inplace(xs, hres, lnp, R, d, p.eps, wave, lane);
+    ln_inplace(xs, Kd, hres, lnp, R, d, p.eps, wave, lane);
     __syncthreads();
-    if (c1 < d) {
-      int idx; bool owner;
-      float v = gemv_reduce<1>(wsml, xs, R, d, lane, idx, owner);
-      if (owner) pack[idx * 4 + wave] = f2bf(v + biasl[wave]);
-    }
-    __syncthreads();
+    mfma_finish<false>(mfma_share<false>(wsml, xs, Kd, R, d, wave, lane), red, biasl, VACNIC_ACT_NONE, pack, R, tid, wave, lane);
     TR3(3);
     if (wg < t_dd) slot_put(srs, A_CQ * SLOT_ARR + (unsigned)wg * SLOT_STRIDE, pack, R * 4, tg + 4, tid);
-    w_issue<1>(wsml, mkrs(ly.w_co, wb_dd), d, d, c1, lane); bias_issue(biasl, ly.b_co, d, wg * 4, 4, wave, lane);
+    w4_issue(wsml, mkrs(ly.w_co, wb_dd), d, d, wg * 4, wave, lane); bias_issue(biasl, ly.b_co, d, wg * 4, 4, wave, lane);
     // ---- P5: cross-attention of pair wg over the encoder K/V
     phase = li * 8 + 4;
     if (wg < npair) {
@@ -1080,95 +1131,47 @@ __global__ __launch_bounds__(NTHR) void decoder_step_slots_kernel(DecP p) {
     }
     // ---- P6: cross-attention output projection
     phase = li * 8 + 5;
-    gather_ctx(srs, CTX_ARR0 + CTX_ARR, npair, H, tg + 5, xs, d, tid, pc);
+    gather_ctx(srs, CTX_ARR0 + CTX_ARR, npair, H, tg + 5, xs, Kd, tid, pc);
     SYNC_OR_QUIT();
     TR3(1);
-    if (c1 < d) {
-      int idx; bool owner;
-      float v = gemv_reduce<1>(wsml, xs, R, d, lane, idx, owner);
-      if (owner) pack[idx * 4 + wave] = f2bf(v + biasl[wave]);
-    }
-    __syncthreads();
+    mfma_finish<false>(mfma_share<false>(wsml, xs, Kd, R, d, wave, lane), red, biasl, VACNIC_ACT_NONE, pack, R, tid, wave, lane);
     TR3(3);
     if (wg < t_dd) slot_put(srs, A_CO * SLOT_ARR + (unsigned)wg * SLOT_STRIDE, pack, R * 4, tg + 6, tid);
-    w_issue<4>(wbig, mkrs(ly.w_fc1, wb_fd), F, d, c4, lane); bias_issue(biasl, ly.b_fc1, F, wg * 16, 16, wave, lane);
+    w16_issue(wbig, mkrs(ly.w_fc1, wb_fd), F, d, wg * 16, wave, lane); bias_issue(biasl, ly.b_fc1, F, wg * 16, 16, wave, lane);
     ln_issue(lnp, ly.ln_cross_g, ly.ln_cross_b, d, wave, lane);
     // ---- P7: post-LN of the cross-attention block, fc1 + GELU
     phase = li * 8 + 6;
-    gather_cols<6>(srs, A_CO * SLOT_ARR, t_dd, R, 2, tg + 6, xs, d, tid, pc);
+    gather_cols<6>(srs, A_CO * SLOT_ARR, t_dd, R, 2, tg + 6, xs, Kd, tid, pc);
     SYNC_OR_QUIT();
     TR3(1);
-    ln_inplace(xs, hres, lnp, R, d, p.eps, wave, lane);
+    ln_inplace(xs, Kd, hres, lnp, R, d, p.eps, wave, lane);
     __syncthreads();
-    if (c4 < F) {
-      int idx; bool owner;
-      float v = gemv_reduce<4>(wbig, xs, R, d, lane, idx, owner);
-      if (owner) pack[(idx >> 2) * 16 + wave * 4 + (idx & 3)] = f2bf(act_fwd(VACNIC_ACT_GELU, v + biasl[wave * 4 + (idx & 3)]));
-    }
-    __syncthreads();
+    mfma_finish<true>(mfma_share<true>(wbig, xs, Kd, R, d, wave, lane), red, biasl, VACNIC_ACT_GELU, pack, R, tid, wave, lane);
     TR3(3);
     if (wg < t_f) slot_put(srs, A_FC1 * SLOT_ARR + (unsigned)wg * SLOT_STRIDE, pack, R * 16, tg + 7, tid);
-    w2_issue(wbig, mkrs(ly.w_fc2, wb_fd), d, F, wg * 4, wave, lane); bias_issue(biasl, ly.b_fc2, d, wg * 4, 4, wave, lane);
-    // ---- P8: fc2 (4 columns per workgroup, the waves split K and meet in LDS: gemm_skinny_kernel<8, 4, 4>)
+    w4_issue(wbig, mkrs(ly.w_fc2, wb_fd), d, F, wg * 4, wave, lane); bias_issue(biasl, ly.b_fc2, d, wg * 4, 4, wave, lane);
+    // ---- P8: fc2
     phase = li * 8 + 7;
-    gather_cols<22>(srs, A_FC1 * SLOT_ARR, t_f, R, 4, tg + 7, xs, F, tid, pc);
+    gather_cols<22>(srs, A_FC1 * SLOT_ARR, t_f, R, 4, tg + 7, xs, Kf, tid, pc);
     SYNC_OR_QUIT();
     TR3(1);
-    {
-      float acc[32];
-#pragma unroll
-      for (int i = 0; i < 32; ++i) acc[i] = 0.f;
-      const int nchunk = F >> 3;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int ch = lane + 64 * wave + 256 * i;
-        if (ch < nchunk) {
-          float wv[4][8];
-#pragma unroll
-          for (int c = 0; c < 4; ++c) unpack8(w_get(wbig, c * 2 + i, lane), wv[c]);
-#pragma unroll
-          for (int m = 0; m < MR; ++m) {
-            if (m < R) {
-              float xv[8];
-              unpack8(*(const u32x4*)(xs + (size_t)m * F + ch * 8), xv);
-#pragma unroll
-              for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[m * 4 + c] += xv[j] * wv[c][j];
-            }
-          }
-        }
-      }
-      int idx; bool owner;
-      float v = bfly32(acc, lane, idx, owner);
-      if (owner) part[wave][idx] = v;
-      __syncthreads();
-      if (wave == 0 && owner) {
-        v = 0.f;
-#pragma unroll
-        for (int w = 0; w < NWAVE; ++w) v += part[w][idx];
-        pack[idx] = f2bf(v + biasl[idx & 3]);                   // idx = row * 4 + column
-      }
-    }
-    __syncthreads();
+    mfma_finish<false>(mfma_share<false>(wbig, xs, Kf, R, F, wave, lane), red, biasl, VACNIC_ACT_NONE, pack, R, tid, wave, lane);
     TR3(3);
     if (wg < t_dd) slot_put(srs, A_FC2 * SLOT_ARR + (unsigned)wg * SLOT_STRIDE, pack, R * 4, tg + 8, tid);
+    ln_issue(lnp, ly.ln_final_g, ly.ln_final_b, d, wave, lane);
     if (li + 1 < p.L) {
       const vacnic_decoder_layer nx = p.layers[li + 1];
-      w_issue<4>(wbig, mkrs(nx.w_kvq, 3 * wb_dd), 3 * d, d, c4, lane); bias_issue(biasl, nx.b_kvq, 3 * d, wg * 16, 16, wave, lane);
-      ln_issue(lnp, ly.ln_final_g, ly.ln_final_b, d, wave, lane);
+      w16_issue(wbig, mkrs(nx.w_kvq, 3 * wb_dd), 3 * d, d, wg * 16, wave, lane); bias_issue(biasl, nx.b_kvq, 3 * d, wg * 16, 16, wave, lane);
     }
   }
-  // workgroup 0 hands the last layer's (block output, residual) pair to the LM-head kernel and bumps the launch nonce
+  // workgroup 0 applies the last layer's final LayerNorm, hands the hidden rows to the LM-head kernel and bumps the launch nonce
   if (wg == 0) {
     phase = p.L * 8;
-    gather_cols<6>(srs, A_FC2 * SLOT_ARR, t_dd, R, 2, tag0 + (unsigned)(p.L - 1) * 8u + 8u, xs, d, tid, pc);
+    gather_cols<6>(srs, A_FC2 * SLOT_ARR, t_dd, R, 2, tag0 + (unsigned)(p.L - 1) * 8u + 8u, xs, Kd, tid, pc);
     SYNC_OR_QUIT();
-    bf16_t* hout = (p.L & 1) ? p.hb1 : p.hb0;
-    for (int c = tid; c < R * (d >> 3); c += NTHR) {
-      *(u32x4*)(p.o + (size_t)c * 8) = *(const u32x4*)(xs + (size_t)c * 8);
-      *(u32x4*)(hout + (size_t)c * 8) = *(const u32x4*)(hres + (size_t)c * 8);
-    }
+    ln_inplace(xs, Kd, hres, lnp, R, d, p.eps, wave, lane);
+    __syncthreads();
+    for (int c = tid; c < R * (d >> 3); c += NTHR) *(u32x4*)(p.o + (size_t)c * 8) = *(const u32x4*)(hres + (size_t)c * 8);
     if (tid == 0) __hip_atomic_store(p.bar + BAR_NONCE, (tag0 >> 10) + 1u, __ATOMIC_RELAXED, AGENT);
   }
 }
@@ -1214,7 +1217,11 @@ extern "C" int vacnic_decoder_step(const vacnic_decoder_step_args* a, void* stre
   const int64_t tkmax = a->S > a->t + 1 ? a->S : a->t + 1;
   const bool use_slots = a->slots != nullptr;
   size_t lds = (size_t)p.xs_bytes + (size_t)NWAVE * (WBIG + WSMALL) + (size_t)(2048 + 64) * 4 + (size_t)(tkmax + NWAVE * 64 + 8) * 4;
-  if (use_slots) lds += (size_t)MR * 1024 * 2 + 160 * 2 + 192 * 2;
+  if (use_slots) {
+    p.xs_bytes = (unsigned)(a->R * (kmax + 8) * 2);
+    lds = (size_t)p.xs_bytes + (size_t)NWAVE * (WBIG + WSMALL) + (size_t)(2048 + 64) * 4 + (size_t)MR * 1024 * 2 + 160 * 2 + 192 * 2 + 1024 * 4 +
+          (size_t)(tkmax + NWAVE * 64 + 8) * 4;
+  }
   VCHECK(lds <= 150 * 1024, VACNIC_UNSUPPORTED, "decoder_step: LDS budget");
   static bool lds_set[2] = {false, false};
   if (lds > 65536 - 1024 && !lds_set[use_slots]) {

@@ -261,7 +261,9 @@ class CachedDecoder:
             else:
                 h, _, _ = K.add_ln_fwd(o.view(R, 1, d), h, layer.final_layer_norm.weight.data, layer.final_layer_norm.bias.data, need_stats=False)
         logits = torch.empty((R, m.V_pad), device=h.device, dtype=torch.float32)
-        if fuse and pend is not None:
+        if self.step_kernel and self.slots is not None:     # slot variant: obuf already holds the final (normalised) hidden rows
+            K.gemm(pend[0], m.emb16_pad, R, m.V, d, bias=m.final_logits_bias.view(-1), out=logits, ldo=m.V_pad, out_mode=1)
+        elif fuse and pend is not None:
             ln_then(pend_ln, m.emb16_pad, m.V, m.final_logits_bias.view(-1), out=logits, ldo=m.V_pad, out_mode=1)
         else:
             K.gemm(h.view(R, d), m.emb16_pad, R, m.V, d, bias=m.final_logits_bias.view(-1), out=logits, ldo=m.V_pad, out_mode=1)
