@@ -352,7 +352,7 @@ int vacnic_beam_step(const vacnic_beam_state* st, const float* top_val, const in
  *            from the VALU kernels: parity to bf16 tolerance, not to the bit).
  *   sync     vacnic_decoder_step_sync_bytes() bytes, zeroed ONCE by the caller; word [sync_bytes / 4 - 64] is an error flag the
  *            kernel raises (and leaves) if a wait times out — check it when the results are read back.
- *   slots    vacnic_decoder_step_slots_bytes() bytes, zeroed ONCE by the caller: the phases hand their results over through
+ *   slots    vacnic_decoder_step_slots_bytes(L) bytes, zeroed ONCE by the caller: the phases hand their results over through
  *            tagged 16-byte units in this buffer (no grid barriers; needs max(d / 4, ffn / 16) <= 256 co-resident workgroups and
  *            d, ffn multiples of 16).  NULL selects the grid-barrier variant (kept as the A/B baseline).
  */
@@ -377,7 +377,7 @@ typedef struct {
                                           [5] arrived at the barrier + next weights issued) */
 } vacnic_decoder_step_args;
 int64_t vacnic_decoder_step_sync_bytes(void);
-int64_t vacnic_decoder_step_slots_bytes(void);
+int64_t vacnic_decoder_step_slots_bytes(int64_t L);
 int vacnic_decoder_step(const vacnic_decoder_step_args* a, void* stream);
 /* dst[r] = src[idx[r]] for rows of row_bytes (multiple of 16): KV-cache beam reorder (_reorder_cache, MFULL:2066-2074). */
 int vacnic_gather_rows(const void* src, void* dst, const int64_t* idx, int64_t rows, int64_t row_bytes, void* stream);

@@ -187,7 +187,7 @@ lib.vacnic_version.argtypes = []
 lib.vacnic_decoder_step_sync_bytes.restype = C.c_int64
 lib.vacnic_decoder_step_sync_bytes.argtypes = []
 lib.vacnic_decoder_step_slots_bytes.restype = C.c_int64
-lib.vacnic_decoder_step_slots_bytes.argtypes = []
+lib.vacnic_decoder_step_slots_bytes.argtypes = [C.c_int64]
 
 _VALUE_ERRORS = (1, 2, 3)   # bad shape / dtype / alignment -> ValueError like the reference's shape checks
 

@@ -396,6 +396,23 @@ __device__ __forceinline__ void stage_ln(rsrc_t osrc, rsrc_t hsrc, const float* 
   }
 }
 
+// wave-wide sum / max through DPP (quad xor 1, xor 2, mirror within 8, mirror within 16: ~8 cycles each instead of a ~100-cycle
+// ds_bpermute per butterfly level) and four v_readlane; a different association than the xor butterfly of wave_sum / wave_max
+#define VAC_DPP(V_, CTRL_) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, V_), CTRL_, 0xf, 0xf, true))
+__device__ __forceinline__ float wave_sum_fast(float v) {
+  v += VAC_DPP(v, 0xB1); v += VAC_DPP(v, 0x4E); v += VAC_DPP(v, 0x141); v += VAC_DPP(v, 0x140);
+  const int iv = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16)) +
+         __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+}
+__device__ __forceinline__ float wave_max_fast(float v) {
+  v = fmaxf(v, VAC_DPP(v, 0xB1)); v = fmaxf(v, VAC_DPP(v, 0x4E)); v = fmaxf(v, VAC_DPP(v, 0x141)); v = fmaxf(v, VAC_DPP(v, 0x140));
+  const int iv = __builtin_bit_cast(int, v);
+  return fmaxf(fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)), __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16))),
+               fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)), __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48))));
+}
+#undef VAC_DPP
+
 // ---- single-query attention of one (row, head) pair (attn_decode_kernel's arithmetic) -------------------------------------
 // q: 64 bf16 at qoff of qrs (coherent).  Keys / values: rows j = 0..Tk-1 at koff + j * ldb / voff + j * ldb of kvrs (AUX = COH
 // for the self-attention cache, whose newest row was written in this launch; 0 for the static cross-attention K/V).
@@ -406,7 +423,7 @@ __device__ __forceinline__ void stage_ln(rsrc_t osrc, rsrc_t hsrc, const float* 
 // (q -> keys -> values per 64 keys: 12 us for a 133-key share); the arithmetic and its order are unchanged.  KU == 0: any length.
 // (slot variant) qlds: the query as 64 bf16 in LDS instead of qrs; knew / vnew: the key / value row of position t_new in LDS — that
 // row of the cache is being written by other workgroups in this launch and is not read.
-struct AttnNew { const bf16_t* qlds; const bf16_t* knew; const bf16_t* vnew; int t_new; };
+struct AttnNew { const bf16_t* qlds; const bf16_t* knew; const bf16_t* vnew; int t_new; bool fast; };     // fast: DPP wave reductions
 
 template <int AUX, int KU>
 __device__ __forceinline__ void attn_share(rsrc_t qrs, unsigned qoff, rsrc_t kvrs, unsigned koff, unsigned voff, unsigned ldb, int k_lo, int k_hi,
@@ -473,13 +490,13 @@ __device__ __forceinline__ void attn_share(rsrc_t qrs, unsigned qoff, rsrc_t kvr
         m = fmaxf(m, sc);
       }
     }
-    m = wave_max(m);
+    m = an.fast ? wave_max_fast(m) : wave_max(m);
     for (int key = k_lo + lane; key < k_hi; key += 64) {
       const float e = __expf(probs[key] - m);
       probs[key] = e;
       l += e;
     }
-    l = wave_sum(l);
+    l = an.fast ? wave_sum_fast(l) : wave_sum(l);
 #pragma unroll
     for (int it = 0; it < KU; ++it) {
       if (k_lo + kg + 64 * it < k_hi) {
@@ -572,7 +589,7 @@ __device__ __forceinline__ void attn_share(rsrc_t qrs, unsigned qoff, rsrc_t kvr
 template <int AUX>
 __device__ __forceinline__ void attn_pair(rsrc_t qrs, unsigned qoff, rsrc_t kvrs, unsigned koff, unsigned voff, unsigned ldb, int Tk,
                                           const uint8_t* km, float scale, rsrc_t ors, unsigned ooff, float* probs, int wave, int lane,
-                                          const AttnNew& an = AttnNew{nullptr, nullptr, nullptr, -1}, float* res8 = nullptr) {
+                                          const AttnNew& an = AttnNew{nullptr, nullptr, nullptr, -1, false}, float* res8 = nullptr) {
   const int nw = Tk >= 256 ? NWAVE : 1;
   const int per = (Tk + nw - 1) / nw;
   const int k_lo = wave * per, k_hi = wave < nw ? min(Tk, k_lo + per) : k_lo;
@@ -791,24 +808,37 @@ __global__ __launch_bounds__(NTHR) void decoder_step_kernel(DecP p) {
 // (l, X).  The residual stream h never leaves the chip: every workgroup normalises all rows anyway and keeps h in LDS.
 //   slot arrays (bytes): 6 GEMV outputs x 256 workgroups x 384  |  2 attention outputs x 128 (row, head) pairs x 192
 constexpr unsigned SLOT_STRIDE = 384, CTX_STRIDE = 192, SLOT_ARR = 256 * SLOT_STRIDE, CTX_ARR0 = 6 * SLOT_ARR, CTX_ARR = 128 * CTX_STRIDE;
-constexpr unsigned SLOTS_BYTES = CTX_ARR0 + 2 * CTX_ARR;
+constexpr unsigned FC1L_ARR0 = CTX_ARR0 + 2 * CTX_ARR;      // + layer * SLOT_ARR: the fc1 outputs get one array PER LAYER (see gather_cols)
+constexpr int MAX_L = 120;
 constexpr int BAR_NONCE = BAR_ERR + 32;
 enum { A_KVQ = 0, A_SO = 1, A_CQ = 2, A_CO = 3, A_FC1 = 4, A_FC2 = 5 };
 
 struct PollCtx { unsigned* errw; int* s_bad; };
 
 // fetch `units` 16-byte units of one slot until all carry `tag` (slots of > 11 units: spin on the last unit first — 1/14 of the traffic)
-template <int UMAX>
+// VIA_L2 (slot arrays written ONCE per launch — the per-layer fc1 arrays): after the coherent poll of the last unit the slot is read
+// with ordinary loads, so the 32 workgroups of an XCD share one fetch of its 57 KB instead of 32 trips to the memory side; the L2
+// was invalidated at kernel start and nobody reads a line before it is written, except that a line fetched while its units were
+// landing may be partially old — the tags catch that and the slot is re-read coherently.
+template <int UMAX, bool VIA_L2 = false>
 __device__ __forceinline__ bool slot_fetch(rsrc_t srs, unsigned off, int units, unsigned tag, u32x4 (&un)[UMAX], const PollCtx& pc) {
   const long long t0 = wall_clock64();
   unsigned spins = 0;
+  bool plain = VIA_L2;
   for (;;) {
     bool ok = true;
     if (units > 11) ok = cld(srs, off + (unsigned)(units - 1) * 16u)[3] == tag;
     if (ok) {
+      if (plain) {
 #pragma unroll
-      for (int u = 0; u < UMAX; ++u)
-        if (u < units) un[u] = cld(srs, off + u * 16);
+        for (int u = 0; u < UMAX; ++u)
+          if (u < units) un[u] = __builtin_amdgcn_raw_buffer_load_b128(srs, off + u * 16, 0, 0);
+        plain = false;
+      } else {
+#pragma unroll
+        for (int u = 0; u < UMAX; ++u)
+          if (u < units) un[u] = cld(srs, off + u * 16);
+      }
 #pragma unroll
       for (int u = 0; u < UMAX; ++u)
         if (u < units) ok = ok && un[u][3] == tag;
@@ -823,13 +853,13 @@ __device__ __forceinline__ bool slot_fetch(rsrc_t srs, unsigned off, int units, 
 }
 
 // consumer of a GEMV output [R][N]: thread i polls producer i's slot (ncw = 1 << lg columns x R rows) and scatters it into xs
-template <int UMAX>
+template <int UMAX, bool VIA_L2 = false>
 __device__ __forceinline__ void gather_cols(rsrc_t srs, unsigned arr, int nslots, int R, int lg, unsigned tag, bf16_t* xs, int K, int tid,
                                             const PollCtx& pc) {
   if (tid < nslots) {
     const int ncw = 1 << lg, nval = R * ncw, units = (nval + 5) / 6;
     u32x4 un[UMAX];
-    if (slot_fetch<UMAX>(srs, arr + (unsigned)tid * SLOT_STRIDE, units, tag, un, pc)) {
+    if (slot_fetch<UMAX, VIA_L2>(srs, arr + (unsigned)tid * SLOT_STRIDE, units, tag, un, pc)) {
 #pragma unroll
       for (int u = 0; u < UMAX; ++u)
 #pragma unroll
@@ -887,16 +917,6 @@ __device__ __forceinline__ void slot_put(rsrc_t srs, unsigned off, const unsigne
 //   16-row tile: piece s of wave w = MFMA step kk = w * per + s: lane l <- W[n0 + (l & 15)][8 * (4 kk + (l >> 4)) .. + 8]
 //   4-row tile:  piece s of wave w covers 4 steps: lane l <- W[n0 + (l & 3)][8 * (16 (w * per4 + s) + (l >> 2)) .. + 8]
 // Sums differ from the VALU path in the last fp32 bits (different association).
-__device__ __forceinline__ float wave_sum_fast(float v) {
-  // quad xor 1, xor 2, mirror within 8, mirror within 16 (DPP: ~8 cycles each instead of a ~100-cycle ds_bpermute), then the 4 rows
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
-  const int iv = __builtin_bit_cast(int, v);
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16)) +
-         __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
-}
 __device__ __forceinline__ int steps_per_wave(int K) { return ((K + 31) / 32 + NWAVE - 1) / NWAVE; }
 
 __device__ __forceinline__ void w16_issue(char* wl, rsrc_t wrs, int N, int K, int n0, int wave, int lane) {
@@ -1031,7 +1051,7 @@ __global__ __launch_bounds__(NTHR) void decoder_step_slots_kernel(DecP p) {
   if (tid == 0) s_bad = 0;
   const PollCtx pc = {p.bar + BAR_ERR, &s_bad};
   const unsigned tag0 = __hip_atomic_load(p.bar + BAR_NONCE, __ATOMIC_RELAXED, AGENT) << 10;
-  const rsrc_t srs = mkrs(p.slots, SLOTS_BYTES);
+  const rsrc_t srs = mkrs(p.slots, FC1L_ARR0 + (unsigned)p.L * SLOT_ARR);
   const rsrc_t rs_cache = mkrs(p.cache, p.cache_bytes);
   const unsigned row_b = (unsigned)p.Tstride * 2u;
   const unsigned wb_dd = (unsigned)(d * d * 2), wb_fd = (unsigned)(F * d * 2);
@@ -1078,7 +1098,7 @@ __global__ __launch_bounds__(NTHR) void decoder_step_slots_kernel(DecP p) {
       SYNC_OR_QUIT();
       TR3(1);
       const unsigned rb = lay_b + (unsigned)r * row_b + (unsigned)h * 128u;
-      const AttnNew an = {qkvn + 128, qkvn, qkvn + 64, p.t};
+      const AttnNew an = {qkvn + 128, qkvn, qkvn + 64, p.t, true};
       float res[8];
       attn_pair<0>(rs_cache, 0u, rs_cache, rb, rb + (unsigned)d * 2u, (unsigned)(2 * d) * 2u, p.t + 1, nullptr, p.scale, rs_cache, 0u, probs,
                    wave, lane, an, res);
@@ -1119,7 +1139,7 @@ __global__ __launch_bounds__(NTHR) void decoder_step_slots_kernel(DecP p) {
       const unsigned kv_rows = ly.cross_bs == 0 ? 1u : (unsigned)R;
       const rsrc_t rs_kv = mkrs(ly.cross_kv, kv_rows * (unsigned)p.S * (unsigned)(2 * d) * 2u);
       const unsigned kb = (unsigned)r * (unsigned)ly.cross_bs * 2u + (unsigned)h * 128u;
-      const AttnNew an = {qkvn + 128, nullptr, nullptr, -1};
+      const AttnNew an = {qkvn + 128, nullptr, nullptr, -1, true};
       float res[8];
       attn_pair<0>(rs_kv, 0u, rs_kv, kb, kb + (unsigned)d * 2u, (unsigned)(2 * d) * 2u, p.S, p.enc_mask ? p.enc_mask + (size_t)r * p.S : nullptr,
                    p.scale, rs_kv, 0u, probs, wave, lane, an, res);
@@ -1148,11 +1168,11 @@ __global__ __launch_bounds__(NTHR) void decoder_step_slots_kernel(DecP p) {
     __syncthreads();
     mfma_finish<true>(mfma_share<true>(wbig, xs, Kd, R, d, wave, lane), red, biasl, VACNIC_ACT_GELU, pack, R, tid, wave, lane);
     TR3(3);
-    if (wg < t_f) slot_put(srs, A_FC1 * SLOT_ARR + (unsigned)wg * SLOT_STRIDE, pack, R * 16, tg + 7, tid);
+    if (wg < t_f) slot_put(srs, FC1L_ARR0 + (unsigned)li * SLOT_ARR + (unsigned)wg * SLOT_STRIDE, pack, R * 16, tg + 7, tid);
     w4_issue(wbig, mkrs(ly.w_fc2, wb_fd), d, F, wg * 4, wave, lane); bias_issue(biasl, ly.b_fc2, d, wg * 4, 4, wave, lane);
     // ---- P8: fc2
     phase = li * 8 + 7;
-    gather_cols<22>(srs, A_FC1 * SLOT_ARR, t_f, R, 4, tg + 7, xs, Kf, tid, pc);
+    gather_cols<22, true>(srs, FC1L_ARR0 + (unsigned)li * SLOT_ARR, t_f, R, 4, tg + 7, xs, Kf, tid, pc);
     SYNC_OR_QUIT();
     TR3(1);
     mfma_finish<false>(mfma_share<false>(wbig, xs, Kf, R, F, wave, lane), red, biasl, VACNIC_ACT_NONE, pack, R, tid, wave, lane);
@@ -1179,7 +1199,7 @@ __global__ __launch_bounds__(NTHR) void decoder_step_slots_kernel(DecP p) {
 }  // namespace
 
 extern "C" int64_t vacnic_decoder_step_sync_bytes(void) { return (int64_t)(BAR_NONCE + 32) * 4; }
-extern "C" int64_t vacnic_decoder_step_slots_bytes(void) { return (int64_t)SLOTS_BYTES; }
+extern "C" int64_t vacnic_decoder_step_slots_bytes(int64_t L) { return (int64_t)FC1L_ARR0 + (L < 1 ? 1 : L) * (int64_t)SLOT_ARR; }
 
 extern "C" int vacnic_decoder_step(const vacnic_decoder_step_args* a, void* stream) {
   VCHECK(a && a->layers && a->cache && a->h0 && a->hbuf[0] && a->hbuf[1] && a->obuf && a->ctx && a->qbuf && a->fbuf && a->sync,
@@ -1235,7 +1255,7 @@ extern "C" int vacnic_decoder_step(const vacnic_decoder_step_args* a, void* stre
   if (use_slots) {
     // one workgroup per 4 columns of a d-wide projection / 16 columns of the FFN: every launched workgroup produces in the last
     // layer's fc1 or fc2, both consumed by workgroup 0 before it bumps the launch nonce
-    VCHECK((a->d & 15) == 0 && (a->F & 15) == 0 && a->L <= 120, VACNIC_UNSUPPORTED, "decoder_step (slots): d, F multiples of 16, L <= 120");
+    VCHECK((a->d & 15) == 0 && (a->F & 15) == 0 && a->L <= MAX_L, VACNIC_UNSUPPORTED, "decoder_step (slots): d, F multiples of 16, L <= 120");
     const int64_t G = a->d / 4 > a->F / 16 ? a->d / 4 : a->F / 16;
     VCHECK(G <= 256 && G <= n_cu && a->R * a->H <= 128 && a->R * a->H <= G, VACNIC_UNSUPPORTED,
            "decoder_step (slots): needs max(d / 4, ffn / 16) <= min(256, CUs) co-resident workgroups");

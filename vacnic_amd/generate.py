@@ -137,7 +137,7 @@ class CachedDecoder:
             self.slots = None
             if (os.environ.get("VACNIC_DECODE_BARRIER", "0") != "1" and d % 16 == 0 and F % 16 == 0 and G <= min(256, cus)
                     and rows * self.H <= min(128, G) and self.L <= 120):
-                self.slots = torch.zeros(int(_lib.lib.vacnic_decoder_step_slots_bytes()), device=dev, dtype=torch.uint8)
+                self.slots = torch.zeros(int(_lib.lib.vacnic_decoder_step_slots_bytes(self.L)), device=dev, dtype=torch.uint8)
             self.hbuf = [torch.zeros((rows, d), device=dev, dtype=BF16) for _ in range(2)]
             self.obuf, self.ctxb, self.qbuf = (torch.zeros((rows, d), device=dev, dtype=BF16) for _ in range(3))
             self.fbuf = torch.zeros((rows, F), device=dev, dtype=BF16)
