@@ -379,8 +379,12 @@ typedef struct {
 int64_t vacnic_decoder_step_sync_bytes(void);
 int64_t vacnic_decoder_step_slots_bytes(int64_t L);
 int vacnic_decoder_step(const vacnic_decoder_step_args* a, void* stream);
-/* dst[r] = src[idx[r]] for rows of row_bytes (multiple of 16): KV-cache beam reorder (_reorder_cache, MFULL:2066-2074). */
-int vacnic_gather_rows(const void* src, void* dst, const int64_t* idx, int64_t rows, int64_t row_bytes, void* stream);
+/* dst[r][:row_bytes] = src[g][:row_bytes] for rows row_stride_bytes apart (0 = row_bytes; both multiples of 16): KV-cache beam
+ * reorder (_reorder_cache, MFULL:2066-2074).  period == 0: g = idx[r]; period > 0: g = (r / period) * period + idx[r % period] —
+ * one beam permutation idx[period] applied to every layer's block of rows.  Copying only the filled prefix of a cache row
+ * (row_bytes < row_stride_bytes) halves the traffic of the reorder on average. */
+int vacnic_gather_rows(const void* src, void* dst, const int64_t* idx, int64_t rows, int64_t row_bytes, int64_t row_stride_bytes,
+                       int64_t period, void* stream);
 
 /* ---- input pipeline ---- */
 /* uint8 image [B][3][H][W] -> fp32 [B][3][H][W]: torchvision ToTensor (x / 255) then Normalize ((t - mean[c]) / std[c]) of

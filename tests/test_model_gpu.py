@@ -452,6 +452,12 @@ def test_beam_topk_kernel_matches_torch():
     idx = torch.tensor([5, 0, 0, 3, 2, 1]).cuda()
     K.gather_rows(src, dst, idx, 6, 64 * 4)
     assert torch.equal(dst, src[idx])
+    # one beam permutation per block of 3 rows (period), only the first 128 bytes of every 256-byte row (the filled cache prefix)
+    dst2 = torch.full_like(src, -1.0)
+    perm = torch.tensor([2, 0, 0]).cuda()
+    K.gather_rows(src, dst2, perm, 6, 32 * 4, row_stride_bytes=64 * 4, period=3)
+    want = src[torch.tensor([2, 0, 0, 5, 3, 3])]
+    assert torch.equal(dst2[:, :32], want[:, :32]) and bool((dst2[:, 32:] == -1.0).all())
 
 
 def test_cfg1_bart_base_vit_b32_only_image_full_depth_matches_oracle():

@@ -162,7 +162,7 @@ _PLAIN_FNS = {
     "vacnic_add_bf16": [vp, vp, vp, i64, vp],
     "vacnic_probe_layouts": [vp, vp, i64, vp],
     "vacnic_beam_topk": [vp, vp, vp, i32, i32, i32, i32, vp, vp, i64, i64, i64, i32, i32, vp],
-    "vacnic_gather_rows": [vp, vp, vp, i64, i64, vp],
+    "vacnic_gather_rows": [vp, vp, vp, i64, i64, i64, i64, vp],
     "vacnic_image_u8_normalize": [vp, vp, vp, i64, i64, i64, f32, f32, f32, f32, f32, f32, vp],
     "vacnic_lmhead_ce_rowp": [vp, vp, vp, vp, f32, vp, i64, i64, vp],
     "vacnic_lmhead_ce_dlogits": [C.POINTER(LmheadCeArgs), i64, i64, vp, i64, vp, vp],

@@ -228,13 +228,15 @@ __global__ __launch_bounds__(TOPK_THREADS) void beam_topk_fast_kernel(const void
   }
 }
 
-// dst[r][:] = src[idx[r]][:], rows of row_bytes (multiple of 16)
+// dst[r][:row_bytes] = src[g][:row_bytes], g = idx[r] (period == 0) or (r / period) * period + idx[r % period] (the same beam
+// permutation applied to every layer's block of `period` rows); rows are `stride` 16-byte chunks apart, `chunks` of them copied
 __global__ __launch_bounds__(256) void gather_rows_kernel(const char* __restrict__ src, char* __restrict__ dst,
-                                                          const int64_t* __restrict__ idx, long rows, long chunks) {
+                                                          const int64_t* __restrict__ idx, long rows, long chunks, long stride, long period) {
   const long total = rows * chunks;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long r = i / chunks, c = i % chunks;
-    ((u32x4*)dst)[r * chunks + c] = ((const u32x4*)src)[idx[r] * chunks + c];
+    const long g = period > 0 ? (r / period) * period + idx[r % period] : idx[r];
+    ((u32x4*)dst)[r * stride + c] = ((const u32x4*)src)[g * stride + c];
   }
 }
 
@@ -438,15 +440,20 @@ extern "C" int vacnic_beam_topk(const void* logits, const float* beam_scores, co
   return VACNIC_OK;
 }
 
-extern "C" int vacnic_gather_rows(const void* src, void* dst, const int64_t* idx, int64_t rows, int64_t row_bytes, void* stream) {
+extern "C" int vacnic_gather_rows(const void* src, void* dst, const int64_t* idx, int64_t rows, int64_t row_bytes, int64_t row_stride_bytes,
+                                  int64_t period, void* stream) {
   VCHECK(src && dst && idx, VACNIC_BAD_SHAPE, "gather_rows: null operand");
-  VCHECK((row_bytes & 15) == 0 && aligned16(src) && aligned16(dst), VACNIC_MISALIGNED, "gather_rows: rows must be 16-byte multiples");
+  if (row_stride_bytes == 0) row_stride_bytes = row_bytes;
+  VCHECK((row_bytes & 15) == 0 && (row_stride_bytes & 15) == 0 && aligned16(src) && aligned16(dst), VACNIC_MISALIGNED,
+         "gather_rows: rows must be 16-byte multiples");
+  VCHECK(row_stride_bytes >= row_bytes && period >= 0 && (period == 0 || rows % period == 0), VACNIC_BAD_SHAPE,
+         "gather_rows: stride < row bytes, or rows not a multiple of the period");
   if (rows * row_bytes == 0) return VACNIC_OK;
   const long chunks = row_bytes / 16;
   long nb = (rows * chunks + 255) / 256;
   if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const char*)src, (char*)dst, idx,
-                     (long)rows, chunks);
+                     (long)rows, chunks, (long)(row_stride_bytes / 16), (long)period);
   VLAUNCH_CHECK();
   return VACNIC_OK;
 }

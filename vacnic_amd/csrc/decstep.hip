@@ -815,11 +815,13 @@ enum { A_KVQ = 0, A_SO = 1, A_CQ = 2, A_CO = 3, A_FC1 = 4, A_FC2 = 5 };
 
 struct PollCtx { unsigned* errw; int* s_bad; };
 
-// fetch `units` 16-byte units of one slot until all carry `tag` (slots of > 11 units: spin on the last unit first — 1/14 of the traffic)
+// fetch `units` 16-byte units of one slot until all carry `tag`
 // VIA_L2 (slot arrays written ONCE per launch — the per-layer fc1 arrays): after the coherent poll of the last unit the slot is read
 // with ordinary loads, so the 32 workgroups of an XCD share one fetch of its 57 KB instead of 32 trips to the memory side; the L2
 // was invalidated at kernel start and nobody reads a line before it is written, except that a line fetched while its units were
 // landing may be partially old — the tags catch that and the slot is re-read coherently.
+// (Keeping two or three probes of a slot in flight, ~0.4 us apart, to see it sooner was measured SLOWER: 555 -> 679 us per token —
+// the memory side is sensitive to the extra poll traffic of 65 K threads.)
 template <int UMAX, bool VIA_L2 = false>
 __device__ __forceinline__ bool slot_fetch(rsrc_t srs, unsigned off, int units, unsigned tag, u32x4 (&un)[UMAX], const PollCtx& pc) {
   const long long t0 = wall_clock64();
@@ -827,7 +829,7 @@ __device__ __forceinline__ bool slot_fetch(rsrc_t srs, unsigned off, int units, 
   bool plain = VIA_L2;
   for (;;) {
     bool ok = true;
-    if (units > 11) ok = cld(srs, off + (unsigned)(units - 1) * 16u)[3] == tag;
+    if (units > 11) ok = cld(srs, off + (unsigned)(units - 1) * 16u)[3] == tag;     // long slots: the last unit first (1/14 of the traffic)
     if (ok) {
       if (plain) {
 #pragma unroll

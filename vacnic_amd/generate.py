@@ -273,8 +273,10 @@ class CachedDecoder:
         """before step t: the self-attention caches of all layers follow their beams (one launch; _reorder_cache
         MFULL:2066-2074): cache[(t-1)&1] gathered into cache[t&1]."""
         L, R = self.L, self.rows
-        idx = (self.lidx + beam_idx[None, :]).reshape(-1)
-        K.gather_rows(self.cache[(t - 1) & 1], self.cache[t & 1], idx, L * R, (self.Tmax + 1) * 2 * self.d * 2)
+        # one permutation for every layer's block of R rows (period = R), and only the t positions filled so far (+ the slot where
+        # the per-op path parks q) travel: half the bytes of whole rows on average, no index arithmetic on the host side
+        K.gather_rows(self.cache[(t - 1) & 1], self.cache[t & 1], beam_idx, L * R, (t + 1) * 2 * self.d * 2,
+                      row_stride_bytes=(self.Tmax + 1) * 2 * self.d * 2, period=R)
 
 
 class DecodeSession:
@@ -313,6 +315,7 @@ class DecodeSession:
             self.bans_s = torch.full((R, L), -1, **i32)
         self.seq = torch.zeros((2, R, L), **i32)
         self.done_d = torch.zeros(B, **i32)
+        self.h_done = torch.zeros(B, dtype=torch.int32).pin_memory()
         self.hyp_cnt = torch.zeros(B, **i32)
         self.hyp_worst = torch.zeros(B, device=dev, dtype=torch.float64)
         self.hyp_score = torch.zeros((B, nb), device=dev, dtype=torch.float64)
@@ -333,6 +336,7 @@ class DecodeSession:
         st = K._stream()
         _lib.check(_lib.lib.vacnic_beam_init(_lib.C.byref(self.beam), int(start), st))
         steps = 0
+        pending = None                                       # (event, pinned copy of the done flags): polled without blocking the launches
         for t in range(self.max_length - 1):
             if use_graphs and self.captions > 0:
                 g = self.graphs.get(t)
@@ -348,8 +352,17 @@ class DecodeSession:
             else:
                 self.body(t)
             steps = t + 1
-            if t % 8 == 7 and t + 1 < self.max_length - 1 and bool(self.done_d.all().item()):     # one tiny sync every 8 positions
-                break
+            # early stop: the done flags are copied out every 8th position and looked at when the copy has landed, so the launch
+            # path never waits; positions enqueued in the meantime only pad finished items (BeamSearchScorer.process on done batches)
+            if pending is not None and pending[0].query():
+                if bool(pending[1].all()):
+                    break
+                pending = None
+            if pending is None and t % 8 == 7 and t + 1 < self.max_length - 1:
+                self.h_done.copy_(self.done_d, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                pending = (ev, self.h_done)
         cur_len = steps + 1                                  # tokens in every live history
         seqs = self.seq[steps & 1].cpu()
         self.dec.check_step_kernel()

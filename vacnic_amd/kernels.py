@@ -474,5 +474,5 @@ def image_u8_normalize(img_u8, flip=None, mean=(0.48145466, 0.4578275, 0.4082107
     return out
 
 
-def gather_rows(src, dst, idx, rows, row_bytes):
-    call("vacnic_gather_rows", _p(src), _p(dst), _p(idx), rows, row_bytes, _stream())
+def gather_rows(src, dst, idx, rows, row_bytes, row_stride_bytes=0, period=0):
+    call("vacnic_gather_rows", _p(src), _p(dst), _p(idx), rows, row_bytes, row_stride_bytes, period, _stream())
