@@ -22,13 +22,16 @@ with torch.no_grad():
     ids = torch.randint(3, 50000, (R, 1), generator=g).cuda()
     for t in range(30):
         dec.step(ids, t)
-    for wg in (0, 100, 255):
+    for wg in (0, 100, 255) if len(sys.argv) < 2 else (0,):
         dec.trace = torch.zeros((8 * L + 1) * 8, device="cuda", dtype=torch.int64)
         dec.trace_wg = wg
         dec.step(ids, 30)
         torch.cuda.synchronize()
         tr = dec.trace.cpu().view(-1, 8).double() / 100.0          # us
         if dec.slots is not None:
+            raw = dec.trace.cpu().view(-1, 8)
+            dw, dc = (raw[8 * L, 6] - raw[8 * L, 4]).item(), (raw[8 * L, 7] - raw[8 * L, 5]).item()
+            print(f"shader clock during the kernel: {dc} cycles in {dw / 100.0:.1f} us = {dc / (dw / 100.0) / 1e3:.2f} GHz")
             print(f"workgroup {wg} (slot variant): kernel span {(tr[8 * L - 1, 3] - tr[0, 1]).item():.1f} us over {8 * L} phases")
             print("  phase            wait+gather   compute+pack    total   (attention phases: pair workgroups only)")
             for k in range(8):
@@ -38,7 +41,9 @@ with torch.no_grad():
                 prev = lambda ph: max(tr[q, 3].item() for q in range(max(0, ph - 3), ph))
                 ga = sum(tr[ph, 1].item() - prev(ph) for ph in rows) / len(rows)
                 co = sum((tr[ph, 3] - tr[ph, 1]).item() for ph in rows) / len(rows)
-                print(f"  {names[k]:14s} {ga:11.2f} {co:14.2f} {ga + co:8.2f}")
+                ln = [ph for ph in rows if tr[ph, 2] > 0]
+                lns = f"   (LayerNorm {sum((tr[ph, 2] - tr[ph, 1]).item() for ph in ln) / len(ln):.2f})" if ln else ""
+                print(f"  {names[k]:14s} {ga:11.2f} {co:14.2f} {ga + co:8.2f}{lns}")
             continue
         print(f"workgroup {wg}: kernel span {(tr[8 * L - 1, 3] - tr[0, 1]).item():.1f} us over {8 * L} phases")
         print("  phase            stage   compute+store  store-ack  arrive+issue  barrier-wait   total")

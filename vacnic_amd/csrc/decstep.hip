@@ -1059,6 +1059,7 @@ __global__ __launch_bounds__(NTHR) void decoder_step_slots_kernel(DecP p) {
   const unsigned wb_dd = (unsigned)(d * d * 2), wb_fd = (unsigned)(F * d * 2);
   const int npair = R * H, t_dd = d >> 2, t_3d = (3 * d) >> 4, t_f = F >> 4;    // producers of an N = d / 3d / F phase
   int phase = 0;
+  if (p.trace && wg == p.trace_wg && tid == 0) { p.trace[p.L * 64 + 4] = wall_clock64(); p.trace[p.L * 64 + 5] = clock64(); }
   {
     const vacnic_decoder_layer l0 = p.layers[0];
     w16_issue(wbig, mkrs(l0.w_kvq, 3 * wb_dd), 3 * d, d, wg * 16, wave, lane);
@@ -1127,6 +1128,7 @@ __global__ __launch_bounds__(NTHR) void decoder_step_slots_kernel(DecP p) {
     TR3(1);
     ln_inplace(xs, Kd, hres, lnp, R, d, p.eps, wave, lane);
     __syncthreads();
+    TR3(2);
     mfma_finish<false>(mfma_share<false>(wsml, xs, Kd, R, d, wave, lane), red, biasl, VACNIC_ACT_NONE, pack, R, tid, wave, lane);
     TR3(3);
     if (wg < t_dd) slot_put(srs, A_CQ * SLOT_ARR + (unsigned)wg * SLOT_STRIDE, pack, R * 4, tg + 4, tid);
@@ -1168,6 +1170,7 @@ __global__ __launch_bounds__(NTHR) void decoder_step_slots_kernel(DecP p) {
     TR3(1);
     ln_inplace(xs, Kd, hres, lnp, R, d, p.eps, wave, lane);
     __syncthreads();
+    TR3(2);
     mfma_finish<true>(mfma_share<true>(wbig, xs, Kd, R, d, wave, lane), red, biasl, VACNIC_ACT_GELU, pack, R, tid, wave, lane);
     TR3(3);
     if (wg < t_f) slot_put(srs, FC1L_ARR0 + (unsigned)li * SLOT_ARR + (unsigned)wg * SLOT_STRIDE, pack, R * 16, tg + 7, tid);
@@ -1186,6 +1189,7 @@ __global__ __launch_bounds__(NTHR) void decoder_step_slots_kernel(DecP p) {
       w16_issue(wbig, mkrs(nx.w_kvq, 3 * wb_dd), 3 * d, d, wg * 16, wave, lane); bias_issue(biasl, nx.b_kvq, 3 * d, wg * 16, 16, wave, lane);
     }
   }
+  if (p.trace && wg == p.trace_wg && tid == 0) { p.trace[p.L * 64 + 6] = wall_clock64(); p.trace[p.L * 64 + 7] = clock64(); }
   // workgroup 0 applies the last layer's final LayerNorm, hands the hidden rows to the LM-head kernel and bumps the launch nonce
   if (wg == 0) {
     phase = p.L * 8;
@@ -1193,6 +1197,7 @@ __global__ __launch_bounds__(NTHR) void decoder_step_slots_kernel(DecP p) {
     SYNC_OR_QUIT();
     ln_inplace(xs, Kd, hres, lnp, R, d, p.eps, wave, lane);
     __syncthreads();
+    TR3(2);
     for (int c = tid; c < R * (d >> 3); c += NTHR) *(u32x4*)(p.o + (size_t)c * 8) = *(const u32x4*)(hres + (size_t)c * 8);
     if (tid == 0) __hip_atomic_store(p.bar + BAR_NONCE, (tag0 >> 10) + 1u, __ATOMIC_RELAXED, AGENT);
   }
