@@ -84,6 +84,28 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(const void* __restrict__
 constexpr int TOPK_THREADS = 1024;
 constexpr int TOPK_CAND = 1024;
 
+// wave-wide best under the strict order (value desc, index asc), result in every lane: four DPP compare-exchange steps (quad
+// xor 1, xor 2, mirror within 8, mirror within 16: ~8 cycles each, no ds_bpermute) and a scalar pass over the four rows
+__device__ __forceinline__ void wave_argbest(float& bv, int& bi) {
+#define VAC_STEP(CTRL_)                                                                                                        \
+  {                                                                                                                            \
+    const float ov = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, bv), CTRL_, 0xf, 0xf, true)); \
+    const int oi = __builtin_amdgcn_update_dpp(0, bi, CTRL_, 0xf, 0xf, true);                                                  \
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }                                                                \
+  }
+  VAC_STEP(0xB1) VAC_STEP(0x4E) VAC_STEP(0x141) VAC_STEP(0x140)
+#undef VAC_STEP
+  float rv_ = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bv), 0));
+  int ri_ = __builtin_amdgcn_readlane(bi, 0);
+#pragma unroll
+  for (int row = 1; row < 4; ++row) {
+    const float ov = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bv), 16 * row));
+    const int oi = __builtin_amdgcn_readlane(bi, 16 * row);
+    if (ov > rv_ || (ov == rv_ && oi < ri_)) { rv_ = ov; ri_ = oi; }
+  }
+  bv = rv_; bi = ri_;
+}
+
 __device__ __forceinline__ void block_argmax(float& bv, int& bi, float* rv, int* ri, int lane, int wave) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -173,13 +195,31 @@ __global__ __launch_bounds__(TOPK_THREADS) void beam_topk_fast_kernel(const void
 #pragma unroll
   for (int w = 0; w < TOPK_THREADS / 64; ++w) tot += rv[w];
   const float lse = gm + logf(tot), base = beam_scores ? beam_scores[r] : 0.f;
-  // ---- threshold: K-th largest thread maximum
-  float mine = tmax, T = -INFINITY;
-  for (int k = 0; k < K; ++k) {
-    float bv = mine; int bi = tid;
-    block_argmax(bv, bi, rv, ri, lane, wave);
-    if (bi == tid) mine = -INFINITY;
-    T = bv;
+  // ---- threshold: a lower bound of the K-th best score from K distinct elements
+  float T = -INFINITY;
+  if (K <= TOPK_THREADS / 64) {
+    // K-th largest WAVE maximum (16 waves; the expected number of elements above it is ~15 at V = 50 K): one workgroup barrier and
+    // K wave-level rounds instead of K block-wide arg-max rounds with two barriers each (~1.2 us apiece)
+    float wv = tmax; int wi = tid;
+    wave_argbest(wv, wi);
+    __syncthreads();
+    if (lane == 0) rv[wave] = wv;
+    __syncthreads();
+    float x = lane < TOPK_THREADS / 64 ? rv[lane] : -INFINITY;
+    for (int k = 0; k < K; ++k) {
+      float bv = x; int bi = lane;
+      wave_argbest(bv, bi);
+      if (bi == lane) x = -INFINITY;
+      T = bv;
+    }
+  } else {
+    float mine = tmax;                                  // K-th largest thread maximum
+    for (int k = 0; k < K; ++k) {
+      float bv = mine; int bi = tid;
+      block_argmax(bv, bi, rv, ri, lane, wave);
+      if (bi == tid) mine = -INFINITY;
+      T = bv;
+    }
   }
   __syncthreads();
   // ---- pass 2: candidates
@@ -194,6 +234,36 @@ __global__ __launch_bounds__(TOPK_THREADS) void beam_topk_fast_kernel(const void
     });
     __syncthreads();
     overflow = *cnt > TOPK_CAND;
+  }
+  if (!overflow && *cnt <= 256) {
+    // the usual case (a few dozen candidates): wave 0 alone picks the K best, four candidates per lane, no workgroup barriers
+    if (wave == 0) {
+      const int n = *cnt;
+      float cv[4]; int ci[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = lane + 64 * u;
+        cv[u] = c < n ? cand_v[c] : -INFINITY;
+        ci[u] = c < n ? cand_i[c] : 0x7fffffff;
+      }
+      for (int k = 0; k < K; ++k) {
+        float bv = cv[0]; int bi = ci[0];
+#pragma unroll
+        for (int u = 1; u < 4; ++u)
+          if (cv[u] > bv || (cv[u] == bv && ci[u] < bi)) { bv = cv[u]; bi = ci[u]; }
+        wave_argbest(bv, bi);
+        if (bi != 0x7fffffff) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (ci[u] == bi) { cv[u] = -INFINITY; ci[u] = 0x7fffffff; }
+        }
+        if (lane == 0) {
+          top_val[r * K + k] = bv == -INFINITY ? -INFINITY : bv - lse + base;
+          top_idx[r * K + k] = bi == 0x7fffffff ? -1 : bi;
+        }
+      }
+    }
+    return;
   }
   if (!overflow) {
     const int n = *cnt;
