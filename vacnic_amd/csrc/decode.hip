@@ -353,11 +353,30 @@ __global__ __launch_bounds__(64) void beam_step_kernel(BeamP p) {
       int bi = -1; float bv = 0.f; long long bk = 0;
       if (!u0) { bi = lane; bv = v0; bk = k0; }
       if (!u1 && (bi < 0 || v1 > bv || (v1 == bv && k1 < bk))) { bi = lane + 64; bv = v1; bk = k1; }
+      // wave-wide arg-best through DPP (quad xor 1, xor 2, mirror within 8, mirror within 16) + a scalar pass over the four rows:
+      // the 24 ds_bpermute of the xor butterfly per round were most of this kernel's 16 us
+      {
+        int bh = (int)(bk >> 32), bl = (int)(bk & 0xffffffffLL);
+#define VAC_STEP(CTRL_)                                                                                                          \
+        {                                                                                                                        \
+          const int oi = __builtin_amdgcn_update_dpp(0, bi, CTRL_, 0xf, 0xf, true);                                             \
+          const float ov = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, bv), CTRL_, 0xf, 0xf, true)); \
+          const int oh = __builtin_amdgcn_update_dpp(0, bh, CTRL_, 0xf, 0xf, true), ol = __builtin_amdgcn_update_dpp(0, bl, CTRL_, 0xf, 0xf, true); \
+          const long long ok = ((long long)oh << 32) | (unsigned)ol, mk = ((long long)bh << 32) | (unsigned)bl;                  \
+          if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && ok < mk))) { bi = oi; bv = ov; bh = oh; bl = ol; }                   \
+        }
+        VAC_STEP(0xB1) VAC_STEP(0x4E) VAC_STEP(0x141) VAC_STEP(0x140)
+#undef VAC_STEP
+        int ri_ = __builtin_amdgcn_readlane(bi, 0), rh_ = __builtin_amdgcn_readlane(bh, 0), rl_ = __builtin_amdgcn_readlane(bl, 0);
+        float rv_ = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bv), 0));
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const int oi = __shfl_xor(bi, o, 64); const float ov = __shfl_xor(bv, o, 64);
-        const long long ok = ((long long)__shfl_xor((int)(bk >> 32), o, 64) << 32) | (unsigned)__shfl_xor((int)(bk & 0xffffffffLL), o, 64);
-        if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && ok < bk))) { bi = oi; bv = ov; bk = ok; }
+        for (int row = 1; row < 4; ++row) {
+          const int oi = __builtin_amdgcn_readlane(bi, 16 * row), oh = __builtin_amdgcn_readlane(bh, 16 * row), ol = __builtin_amdgcn_readlane(bl, 16 * row);
+          const float ov = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bv), 16 * row));
+          const long long ok = ((long long)oh << 32) | (unsigned)ol, mk = ((long long)rh_ << 32) | (unsigned)rl_;
+          if (oi >= 0 && (ri_ < 0 || ov > rv_ || (ov == rv_ && ok < mk))) { ri_ = oi; rv_ = ov; rh_ = oh; rl_ = ol; }
+        }
+        bi = ri_; bv = rv_; bk = ((long long)rh_ << 32) | (unsigned)rl_;
       }
       if (bi < 0) break;                                    // wave-uniform
       if (bi == lane) u0 = true;
