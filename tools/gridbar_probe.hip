@@ -142,6 +142,65 @@ __global__ __launch_bounds__(256) void probe(unsigned* ctr, unsigned* err, u32x4
   }
 }
 
+
+// ---- XCD-local exchange: the 32 workgroups that share one XCD's L2 synchronise among themselves only.  Payload by plain stores
+// (the vector L1 is write-through, the data lands in the XCD's L2) or sc1 stores, and sc1 loads; the barrier
+// counter / flag of an XCD are touched by that XCD alone.  XCC_ID comes from the hardware register, the rank inside the XCD from a
+// monotonic per-XCD counter (old & 31; old >> 5 must equal the launch number).
+__device__ __forceinline__ int xcc_id() { return (int)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 0xf); }
+
+template <bool PAYLOAD, bool PLAIN_STORE>
+__global__ __launch_bounds__(256) void probe_xcd(unsigned* bar, unsigned* err, u32x4* buf, int nph, unsigned* mism, unsigned base, unsigned launch_no,
+                                                 unsigned* xcd_hist) {
+  const int tid = threadIdx.x;
+  __shared__ int s_x, s_rank, s_bad;
+  if (tid == 0) {
+    s_x = xcc_id();
+    const unsigned old = __hip_atomic_fetch_add(bar + 32 * (40 + s_x), 1u, __ATOMIC_RELAXED, AGENT);
+    s_rank = (int)(old & 31u);
+    s_bad = (old >> 5) != launch_no;
+    if (s_bad) __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, AGENT);
+    if (launch_no == 0) atomicAdd(xcd_hist + s_x * 8 + (blockIdx.x & 7), 1u);
+  }
+  __syncthreads();
+  if (s_bad) return;
+  const int x = s_x, rank = s_rank;
+  unsigned* cnt = bar + 32 * (50 + x);                  // this XCD's arrive counter (monotonic over launches: 32 per phase)
+  unsigned* flag = bar + 32 * (60 + x);
+  const unsigned ph0 = launch_no * (unsigned)nph;
+  u32x4* mybuf = buf + (size_t)x * 2 * 32 * 256;        // [2][32 workgroups][256 threads]
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)mybuf, 0, 2u * 32 * 256 * 16, 0x00020000);
+  unsigned bad = 0;
+  for (int ph = 0; ph < nph; ++ph) {
+    const unsigned half = (ph & 1) * 32 * 256;
+    if (PAYLOAD) __builtin_amdgcn_raw_buffer_store_b128((u32x4){(unsigned)ph + base, (unsigned)rank, (unsigned)tid, 0u}, rs, (half + rank * 256 + tid) * 16, 0, PLAIN_STORE ? 0 : 16);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned gph = ph0 + (unsigned)ph + 1u;
+      if (__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, AGENT) + 1 == gph * 32u) {
+        __hip_atomic_store(flag, gph, __ATOMIC_RELAXED, AGENT);
+      } else {
+        const long long t0 = wall_clock64();
+        while (__builtin_amdgcn_raw_buffer_load_b32(__builtin_amdgcn_make_buffer_rsrc((void*)flag, 0, 4, 0x00020000), 0, 0, 16) < gph) {
+          if (wall_clock64() - t0 > 50000000ll) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, AGENT); s_bad = 1; break; }
+        }
+      }
+    }
+    __syncthreads();
+    if (s_bad) return;
+    if (PAYLOAD) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int src = (rank * 7 + 1 + j * 11) & 31;
+        const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rs, (half + src * 256 + tid) * 16, 0, 16);    // sc1 (sc0 alone hits a stale L1 line: the first version of this probe timed out)
+        if (r[0] != (unsigned)ph + base || r[1] != (unsigned)src || r[2] != (unsigned)tid) ++bad;
+      }
+    }
+  }
+  if (bad) atomicAdd(mism, bad);
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 template <int VARIANT, bool PAYLOAD>
@@ -221,6 +280,33 @@ int main() {
     run2<32, 32, false>("32 groups, 32 flags", G, nph, bar, err, buf, mism);
     run2<16, 16, true>("16 groups, 16 flags + payload", G, nph, bar, err, buf, mism);
     run2<32, 32, true>("32 groups, 32 flags + payload", G, nph, bar, err, buf, mism);
+  }
+  {
+    unsigned* hist; CK(hipMalloc(&hist, 64 * 4)); CK(hipMemset(hist, 0, 64 * 4));
+    CK(hipMemset(bar, 0, 32 * 256 * 4)); CK(hipMemset(err, 0, 256)); CK(hipMemset(mism, 0, 256));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    unsigned launch_no = 0;
+    for (int payload = 0; payload < 3; ++payload) {
+      float best = 1e9f; unsigned base = 900000;
+      for (int rep = 0; rep < 6; ++rep) {
+        base += 7777;
+        CK(hipEventRecord(e0, 0));
+        if (payload == 2) hipLaunchKernelGGL((probe_xcd<true, true>), dim3(256), dim3(256), 0, 0, bar, err, buf, nph, mism, base, launch_no, hist);
+        else if (payload) hipLaunchKernelGGL((probe_xcd<true, false>), dim3(256), dim3(256), 0, 0, bar, err, buf, nph, mism, base, launch_no, hist);
+        else hipLaunchKernelGGL((probe_xcd<false, false>), dim3(256), dim3(256), 0, 0, bar, err, buf, nph, mism, base, launch_no, hist);
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep > 0 && ms < best) best = ms;
+        ++launch_no;
+      }
+      unsigned h_err = 0, h_m = 0;
+      CK(hipMemcpy(&h_err, err, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&h_m, mism, 4, hipMemcpyDeviceToHost));
+      printf("XCD-local barrier (32 workgroups per XCD, L2-coherent)%s  %6.2f us/phase  err=%u mismatches=%u\n", payload == 2 ? " + payload (plain stores)" : payload ? " + payload (sc1 stores)" : "",
+             best * 1e3f / nph, h_err, h_m);
+    }
+    unsigned hh[64]; CK(hipMemcpy(hh, hist, 256, hipMemcpyDeviceToHost));
+    printf("workgroups per XCD (first launch), rows = XCC_ID, columns = blockIdx & 7:\n");
+    for (int x = 0; x < 8; ++x) { printf("  xcc %d:", x); for (int j = 0; j < 8; ++j) printf(" %3u", hh[x * 8 + j]); printf("\n"); }
   }
   return 0;
 }
