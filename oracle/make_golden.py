@@ -246,6 +246,35 @@ def run_generate_case(mfull, train):
     np.savez_compressed(os.path.join(OUT, "generate_small.npz"), **rec)
 
 
+def run_generate_cfg5_case(mfull, train):
+    """configs[4]'s exact call — batch 1, num_beams 5, max_length 50, length_penalty 2.0 (TRAIN:513-520, DDPINF:758-842,
+    run_full_train.sh:10-11) — by transformers' beam search (GenerationMixin, cache-less) over the REFERENCE model carrying the
+    planted-caption weights of oracle/cfg5_fixture.py: with the library defaults, with the hub checkpoints' generation defaults,
+    and each with min_length 49 so that every one of the 50 positions is decoded.  Fixture: tests/golden/generate_cfg5.npz."""
+    from transformers import GenerationMixin
+    from oracle import cfg5_fixture as F5
+    cfg = F5.cfg5_cfg()
+    sd = F5.state_dict(cfg)
+
+    class Oracle(mfull.BartForMultiModalGeneration, GenerationMixin):
+        pass
+    orig = mfull.BartForMultiModalGeneration
+    mfull.BartForMultiModalGeneration = Oracle
+    m = build_ref_model(mfull, cfg, sd)
+    mfull.BartForMultiModalGeneration = orig
+    batch, img = F5.inputs(cfg)
+    src = batch["article_ids"]; mask = train.create_src_mask_bart(src)
+    kw = dict(image_features=img, face_features=batch["face_emb"], face_mask=train.create_src_mask_bart(batch["face_emb"][:, :, -1]),
+              name_ids=batch["names_art_ids"], name_mask=train.create_src_mask_bart(batch["names_art_ids"]), add_ner_ffn=True)
+    rec = {}
+    for name, extra in F5.CASES:
+        out = m.generate(input_ids=src, attention_mask=mask, num_beams=F5.NUM_BEAMS, max_length=F5.MAX_LENGTH,
+                         length_penalty=F5.LENGTH_PENALTY, use_cache=False, do_sample=False, **extra, **kw).sequences
+        rec[name] = out.numpy()
+        print("generate cfg5", name, tuple(out.shape), out[0, :8].tolist(), "...", out[0, -3:].tolist())
+    np.savez_compressed(os.path.join(OUT, "generate_cfg5.npz"), **rec)
+
+
 def run_helpers(train, BatchSoftmax):
     g = torch.Generator().manual_seed(5)
     ids = torch.tensor([[0, 5, 6, 2, 1], [0, 9, 2, 1, 1], [0, 7, -100, 2, 1]])
@@ -397,6 +426,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "generate":
         run_generate_case(mfull, train)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "generate_cfg5":
+        run_generate_cfg5_case(mfull, train)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "collate":
         run_collate()
         return
@@ -410,6 +442,7 @@ def main():
     run_helpers(train, BatchSoftmax)
     run_checkpoint_readback(mfull, train)
     run_generate_case(mfull, train)
+    run_generate_cfg5_case(mfull, train)
     run_clip_crosscheck()
     run_full_case("mfull_d768", mfull, train, BatchSoftmax, small_cfg(), B=3, S=48, T=12, F=3)
     run_full_case("mfull_d1024", mfull, train, BatchSoftmax,

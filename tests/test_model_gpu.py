@@ -425,6 +425,71 @@ def test_beam_search_kv_cache_matches_oracle_and_reference_golden():
     assert torch.equal(a.cpu(), want), (a.tolist(), want.tolist())
 
 
+@pytest.mark.parametrize("variant", ["slots", "barrier", "per_op"])
+def test_config5_batch1_beam5_maxlen50_matches_reference_golden(variant, monkeypatch):
+    """BASELINE configs[4] on its own code path (TRAIN:513-520, DDPINF:758-842, run_full_train.sh:10-11): batch 1, beam 5,
+    length_penalty 2.0, max_length 50 — R = 5 rows, i.e. the persistent single-launch decoder-step kernel (tagged-slot exchange by
+    default, grid-barrier variant, and the kernel-per-op chain as the third leg) with on-device beam bookkeeping, eagerly and as
+    hipGraph capture + replay.  Ids must equal tests/golden/generate_cfg5.npz — transformers' beam search over the REAL
+    reference model — and the oracle's restatement, with the library defaults, with the hub checkpoints' generation defaults
+    (no-repeat 3-grams, early stopping, forced BOS), and with min_length 49 (all 50 positions decoded: the cache ping-pong, the
+    per-layer beam gather and the early-exit poll every 8th position all run to the end).  Weights: oracle/cfg5_fixture.py
+    (a seeded random network with one planted caption per path, so that identical ids is a stable bar for bf16 arithmetic)."""
+    from oracle import cfg5_fixture as F5, vacnic_oracle as O
+    from vacnic_amd import kernels as K, synthetic
+    from vacnic_amd.config import ClipVisionConfig
+    from vacnic_amd.training import build_models
+    gold = np.load(os.path.join(G, "generate_cfg5.npz"))
+    planted = np.load(F5.PLANTED)
+    want_planted = F5.expected(planted)
+    cfg = F5.cfg5_cfg()
+    vcfg = ClipVisionConfig(width=128, layers=1, patch_size=16, image_size=32, output_dim=64)
+    sd = F5.state_dict(cfg, planted)
+    model, _, _ = build_models(cfg, vcfg, init="synthetic",
+                               state_dicts=(sd, synthetic.make_state_dict(synthetic.guide_bart_param_shapes(cfg), seed=2),
+                                            synthetic.make_state_dict(synthetic.clip_visual_param_shapes(vcfg), seed=4, std=0.05)))
+    model.eval()
+    batch, img = F5.inputs(cfg)
+    src = batch["article_ids"]; omask = O.create_src_mask_bart(src)
+    okw = dict(face_features=batch["face_emb"], face_mask=O.create_src_mask_bart(batch["face_emb"][:, :, -1]),
+               name_ids=batch["names_art_ids"], name_mask=O.create_src_mask_bart(batch["names_art_ids"]))
+    dev = {k: v.cuda() for k, v in batch.items()}
+    mask, _ = K.prep_ids(dev["article_ids"], 1)
+    nmask, _ = K.prep_ids(dev["names_art_ids"], 1)
+    monkeypatch.setenv("VACNIC_DECODE_BARRIER", "1" if variant == "barrier" else "0")
+    monkeypatch.setenv("VACNIC_DECODE_PER_OP", "1" if variant == "per_op" else "0")
+
+    def run(extra, **kw):
+        return model.generate(input_ids=dev["article_ids"], attention_mask=mask, num_beams=F5.NUM_BEAMS, max_length=F5.MAX_LENGTH,
+                              length_penalty=F5.LENGTH_PENALTY, image_features=img.cuda(), face_features=dev["face_emb"],
+                              face_mask=K.face_mask(dev["face_emb"]), name_ids=dev["names_art_ids"], name_mask=nmask, add_ner_ffn=True,
+                              **extra, **kw)
+    for name, extra in F5.CASES:
+        want = torch.from_numpy(gold[name])
+        assert want[0].tolist() == want_planted[name], (name, "golden differs from the caption the fixture plants")
+        if variant == "slots" and name in ("plain", "hub_full50"):      # the oracle's own beam search (fp32 CPU, ~15 s per case)
+            ora = O.beam_search_decode(sd, cfg, src, omask, img, F5.NUM_BEAMS, F5.MAX_LENGTH, F5.LENGTH_PENALTY, forced_eos_token_id=2,
+                                       **extra, **okw)
+            assert torch.equal(ora, want), (name, ora.tolist(), want.tolist())
+        got = run(extra)                                                 # eager; on-device beam bookkeeping (the default)
+        assert torch.equal(got.cpu(), want), (variant, name, "eager", got.tolist(), want.tolist())
+        ses = [s_ for s_ in model._decode_sessions.values() if s_.beam is not None and s_.R == F5.NUM_BEAMS]
+        assert ses, "on-device beam bookkeeping was not used"
+        for s_ in ses:                                                   # the code path config 5 runs on
+            assert s_.dec.step_kernel == (variant != "per_op"), (variant, "decoder-step kernel selection")
+            if variant != "per_op":
+                assert (s_.dec.slots is not None) == (variant == "slots"), (variant, "exchange variant")
+        for rep in range(2):                                             # 2nd call captures every position as a hipGraph, 3rd replays
+            again = run(extra)
+            assert torch.equal(again.cpu(), want), (variant, name, "graph", rep, again.tolist(), want.tolist())
+        if variant == "slots":
+            host = run(extra, device_beams=False)                        # host-side BeamSearchScorer bookkeeping over the same kernels
+            assert torch.equal(host.cpu(), want), (variant, name, "host-side scorer", host.tolist(), want.tolist())
+    assert any(s_.graphs for s_ in model._decode_sessions.values()), "graph replay path was not exercised"
+    for s_ in model._decode_sessions.values():
+        s_.dec.check_step_kernel()
+
+
 def test_beam_topk_kernel_matches_torch():
     from vacnic_amd import kernels as K
     V, ld, R, Kc = 50267, 50272, 6, 10

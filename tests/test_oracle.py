@@ -209,3 +209,26 @@ def test_checkpoint_written_by_the_product_is_read_back_by_the_reference():
                                name_ids=batch["names_art_ids"], name_mask=O.create_src_mask_bart(batch["names_art_ids"]))
     check("logits", out["logits"], g)
     assert np.array_equal(out["logits"].argmax(-1).numpy(), g["argmax"])
+
+
+def test_oracle_config5_beam_search_matches_reference_golden():
+    """configs[4] (batch 1, beam 5, max_length 50, length_penalty 2.0): tests/golden/generate_cfg5.npz = transformers' beam search
+    over the REAL reference model with the planted-caption weights of oracle/cfg5_fixture.py; the oracle's restatement of the
+    4.18 bookkeeping must give the same ids (two of the four cases here; the GPU test covers all four against the golden)."""
+    from oracle import cfg5_fixture as F5
+    g = np.load(os.path.join(G, "generate_cfg5.npz"))
+    planted = np.load(F5.PLANTED)
+    exp = F5.expected(planted)
+    cfg = F5.cfg5_cfg()
+    sd = F5.state_dict(cfg, planted)
+    batch, img = F5.inputs(cfg)
+    src = batch["article_ids"]; mask = O.create_src_mask_bart(src)
+    kw = dict(face_features=batch["face_emb"], face_mask=O.create_src_mask_bart(batch["face_emb"][:, :, -1]),
+              name_ids=batch["names_art_ids"], name_mask=O.create_src_mask_bart(batch["names_art_ids"]))
+    for name, extra in F5.CASES:
+        assert g[name][0].tolist() == exp[name], name
+        if name in ("plain", "hub_full50"):
+            out = O.beam_search_decode(sd, cfg, src, mask, img, F5.NUM_BEAMS, F5.MAX_LENGTH, F5.LENGTH_PENALTY, forced_eos_token_id=2,
+                                       **extra, **kw)
+            assert np.array_equal(out.numpy(), g[name]), (name, out.tolist(), g[name].tolist())
+    assert g["plain"].shape[1] == F5.T_EOS + 1 and g["full50"].shape[1] == 50 and g["hub_full50"].shape[1] == 50

@@ -129,6 +129,7 @@ class CachedDecoder:
                             and F % 8 == 0 and self.H * 64 == d and max_length <= 8191)
         self.step_table = None
         self.trace, self.trace_wg = None, 0       # tools/decstep_trace.py: per-phase time stamps of one workgroup
+        self.last_hidden = None
         if self.step_kernel:
             self.sync = torch.zeros(int(_lib.lib.vacnic_decoder_step_sync_bytes()) // 4, device=dev, dtype=torch.int32)
             # tagged-slot exchange (no grid barriers) when the workgroup count fits the GPU; VACNIC_DECODE_BARRIER=1: barrier variant
@@ -261,12 +262,15 @@ class CachedDecoder:
             else:
                 h, _, _ = K.add_ln_fwd(o.view(R, 1, d), h, layer.final_layer_norm.weight.data, layer.final_layer_norm.bias.data, need_stats=False)
         logits = torch.empty((R, m.V_pad), device=h.device, dtype=torch.float32)
+        # last_hidden: the final hidden rows [R, d] behind these logits (diagnostics / fixture construction; overwritten every step)
         if self.step_kernel and self.slots is not None:     # slot variant: obuf already holds the final (normalised) hidden rows
             K.gemm(pend[0], m.emb16_pad, R, m.V, d, bias=m.final_logits_bias.view(-1), out=logits, ldo=m.V_pad, out_mode=1)
+            self.last_hidden = pend[0]
         elif fuse and pend is not None:
-            ln_then(pend_ln, m.emb16_pad, m.V, m.final_logits_bias.view(-1), out=logits, ldo=m.V_pad, out_mode=1)
+            _, self.last_hidden = ln_then(pend_ln, m.emb16_pad, m.V, m.final_logits_bias.view(-1), out=logits, ldo=m.V_pad, out_mode=1)
         else:
             K.gemm(h.view(R, d), m.emb16_pad, R, m.V, d, bias=m.final_logits_bias.view(-1), out=logits, ldo=m.V_pad, out_mode=1)
+            self.last_hidden = h.view(R, d)
         return logits
 
     def reorder(self, beam_idx, t):
