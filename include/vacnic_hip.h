@@ -67,7 +67,9 @@ typedef struct {
   void* out; void* preact; const void* dact_src; const void* residual;
   float* xsum;                    /* optional f32 [M]: xsum[m] += sum_k X(m,k), not scaled by alpha — the bias gradient
                                      (column sums of dY) fused into the weight-gradient GEMM that stages dY anyway
-                                     (replaces the separate reduction autograd runs for nn.Linear.bias, MFULL:449-452) */
+                                     (replaces the separate reduction autograd runs for nn.Linear.bias, MFULL:449-452).
+                                     Implemented for x_kstrided && w_kstrided (the weight-gradient layout) only; any
+                                     other layout returns VACNIC_UNSUPPORTED */
   int64_t M, N, K;
   int64_t ldx, ldw, ldo;
   int32_t x_kstrided, w_kstrided;

@@ -213,3 +213,13 @@ def test_checkpoint_round_trip_reference_names_on_host():
     with pytest.raises(KeyError):
         bad = dict(ck, model={k: v for k, v in ck["model"].items() if k != "lm_head.weight"})
         checkpoint.load_checkpoint(bad, m2, o2)
+
+
+def test_generation_defaults_reject_unknown_checkpoints():
+    """the hub generation defaults are recorded for the checkpoints the reference's scripts name; any other name must not silently
+    decode with bart-large's values (a bart-large-cnn style config.json differs)."""
+    from vacnic_amd.config import generation_defaults
+    assert generation_defaults(None) == generation_defaults("facebook/bart-large")
+    assert generation_defaults("facebook/bart-base")["no_repeat_ngram_size"] == 3
+    with pytest.raises(KeyError):
+        generation_defaults("facebook/bart-large-cnn")

@@ -115,5 +115,12 @@ HUB_GENERATION_DEFAULTS = {
 
 
 def generation_defaults(plm_type=None):
-    """kwargs for generate() that reproduce the reference's `model.generate(num_beams, max_length)` on a hub checkpoint."""
-    return dict(HUB_GENERATION_DEFAULTS.get(plm_type or "facebook/bart-large", HUB_GENERATION_DEFAULTS["facebook/bart-large"]))
+    """kwargs for generate() that reproduce the reference's `model.generate(num_beams, max_length)` on a hub checkpoint.
+    plm_type None = the shipped scripts' facebook/bart-large.  An UNKNOWN checkpoint name raises: its config.json may carry other
+    values (bart-large-cnn: min_length 56, length_penalty 2.0, max_length 142 ...), and decoding it with bart-large's would
+    silently differ from what the reference does — pass the checkpoint's values as explicit generate() keywords instead."""
+    key = plm_type or "facebook/bart-large"
+    if key not in HUB_GENERATION_DEFAULTS:
+        raise KeyError(f"no recorded generation defaults for checkpoint {plm_type!r} (known: {sorted(HUB_GENERATION_DEFAULTS)}); "
+                       "pass no_repeat_ngram_size / early_stopping / forced_bos_token_id / ... explicitly")
+    return dict(HUB_GENERATION_DEFAULTS[key])

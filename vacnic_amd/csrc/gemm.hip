@@ -347,6 +347,8 @@ static int gemm_one(const vacnic_gemm_args* a, int tile_hint, void* stream, int 
   VCHECK(split == 1 || a->out_mode == 2, VACNIC_UNSUPPORTED, "gemm: split_k needs out_mode 2");
   VCHECK(a->bias == nullptr || aligned16(a->bias), VACNIC_MISALIGNED, "gemm: bias must be 16-byte aligned");
   VCHECK(a->ldo >= a->N, VACNIC_BAD_SHAPE, "gemm: ldo < N");
+  VCHECK(!a->xsum || ce_mode || (a->x_kstrided && a->w_kstrided), VACNIC_UNSUPPORTED,
+         "gemm: xsum (row sums of X) is implemented for the weight-gradient layout only (x_kstrided and w_kstrided)");
   if (a->x_kstrided) VCHECK(a->ldx >= ((a->M + 7) & ~7LL), VACNIC_BAD_SHAPE, "gemm: ldx too small for K-strided X");
   else VCHECK(a->ldx >= ((a->K + 7) & ~7LL), VACNIC_BAD_SHAPE, "gemm: ldx < round_up(K, 8) for K-contiguous X");
   if (a->w_kstrided) VCHECK(a->ldw >= ((a->N + 7) & ~7LL), VACNIC_BAD_SHAPE, "gemm: ldw too small for K-strided W");

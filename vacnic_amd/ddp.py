@@ -29,14 +29,22 @@ class GradTracker:
         self.pending = {s: 0 for s in self.starts}
         self.on_ready = None
         self.in_backward = False
+        self._memo = {}
 
     def _bucket_of(self, t):
-        import bisect
-        off = (t.data_ptr() - self.base) // 4
-        lo = self.starts[bisect.bisect_right(self.starts, off) - 1]
-        hi_off = off + t.numel() - 1
-        hi = self.starts[bisect.bisect_right(self.starts, hi_off) - 1]
-        return [s for s in self.starts if lo <= s <= hi]
+        """start offsets of the buckets a gradient view touches.  Gradient views are persistent slices of the arena, so the
+        answer is memoised per (address, length): after the first step expect() / done() cost one dict lookup each."""
+        key = (t.data_ptr(), t.numel())
+        hit = self._memo.get(key)
+        if hit is None:
+            import bisect
+            off = (key[0] - self.base) // 4
+            if off < 0 or off + key[1] > self.arena.n:
+                raise ValueError("GradTracker: tensor is not a view of the gradient arena")
+            lo = bisect.bisect_right(self.starts, off) - 1
+            hi = bisect.bisect_right(self.starts, off + max(key[1], 1) - 1) - 1
+            hit = self._memo[key] = tuple(self.starts[lo:hi + 1])
+        return hit
 
     def expect(self, t):
         if t is None:

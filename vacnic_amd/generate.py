@@ -29,14 +29,17 @@ class GraphedCall:
     encoder / ViT of a caption are ~600 launches of a few microseconds of work each, i.e. bound by the Python launch path
     (5.5 + 2.5 ms per caption eagerly).  First sighting of a signature runs eagerly (warms kernels and lazy buffers), the second
     captures, later ones copy the inputs into the graph's static buffers and replay.  The outputs live in the graph's pool and
-    are overwritten by the next replay — callers consume them before calling again.  A body that cannot be captured (host
-    synchronisation inside) stays eager for that signature."""
+    are overwritten by the next replay — callers consume (or clone) them before calling again.  A body that stream capture
+    rejects (host synchronisation inside) stays eager for that signature, with a warning; any other error is raised."""
 
     def __init__(self, fn, max_entries=8):
         self.fn, self.cache, self.max_entries = fn, {}, max_entries
 
     def __call__(self, *args):
-        key = tuple((tuple(a.shape), a.dtype) if a is not None else None for a in args)
+        from . import streams
+        # the captured launches depend on the stream schedule in force; weights are read in place from the arenas (same
+        # addresses after an optimizer step or a reload), so they are not part of the key
+        key = (streams.enabled(),) + tuple((tuple(a.shape), a.dtype) if a is not None else None for a in args)
         ent = self.cache.get(key)
         if ent is None:
             if len(self.cache) >= self.max_entries:
@@ -52,8 +55,17 @@ class GraphedCall:
             try:
                 with torch.cuda.graph(g):
                     out = self.fn(*static)
-            except RuntimeError:
+            except _lib.VacnicError:
+                raise                                     # a kernel / argument error is a bug, not a capture limitation
+            except RuntimeError as e:
+                # only what stream capture itself rejects (a host synchronisation inside the body, an unsupported call while
+                # capturing) makes the signature eager; anything else is passed on
                 torch.cuda.synchronize()
+                msg = str(e).lower()
+                if not any(w in msg for w in ("captur", "hipgraph", "cudagraph", "graph")):
+                    raise
+                import warnings
+                warnings.warn(f"GraphedCall: {getattr(self.fn, '__name__', 'fn')} stays eager for signature {key}: {e}")
                 self.cache[key] = "eager"
                 return self.fn(*args)
             ent = self.cache[key] = (g, static, out)
@@ -201,8 +213,16 @@ class CachedDecoder:
     def check_step_kernel(self):
         """after the results were read back: did a grid barrier of the step kernel time out?"""
         if self.step_kernel and int(self.sync[-64].item()) != 0:
+            # a timed-out launch left the barrier counters / nonce and (slot variant) units tagged with the aborted nonce behind:
+            # clear BOTH, so that a later launch can never match stale tags, and take this decoder off the step kernel — whoever
+            # keeps using it (a cached DecodeSession) continues on the kernel-per-op chain
             self.sync.zero_()
-            raise RuntimeError("vacnic_decoder_step: a grid barrier timed out (workgroups not co-resident?); results are invalid")
+            if self.slots is not None:
+                self.slots.zero_()
+            self.step_kernel = False
+            self.step_table = None
+            raise RuntimeError("vacnic_decoder_step: a wait inside the step kernel timed out (workgroups not co-resident?); results of "
+                               "this caption are invalid; this decoder falls back to the kernel-per-op chain")
 
     def step(self, ids_t, t):
         """ids_t int64 [rows, 1] (token at position t) -> fp32 logits [rows, V_pad]."""
@@ -470,7 +490,13 @@ def generate(model, input_ids=None, attention_mask=None, num_beams=1, max_length
     ses.dec.begin(enc_h, mask_u8, nb)
     if device_beams:
         # on-device bookkeeping: the positions are enqueued back to back; ONE device->host copy of the final state
-        cur_len, seqs_t, scores_t, done_t, hcnt, hscore, hlen, hseq = ses.run_device(start, use_graphs)
+        try:
+            cur_len, seqs_t, scores_t, done_t, hcnt, hscore, hlen, hseq = ses.run_device(start, use_graphs)
+        except Exception:
+            sessions.pop(key, None)                      # its graphs / buffers may hold a half-finished caption
+            if was_training:
+                model.train()
+            raise
         ses.captions += 1
         out = []
         for b in range(B):
@@ -504,7 +530,13 @@ def generate(model, input_ids=None, attention_mask=None, num_beams=1, max_length
     while True:
         t = cur_len - 1
         bans = [_banned(s_, no_repeat_ngram_size) for s_ in seqs] if no_repeat_ngram_size > 0 else None
-        tv, ti = ses.step(t, [s_[-1] for s_ in seqs], beam_scores, new_src, bans, use_graphs)
+        try:
+            tv, ti = ses.step(t, [s_[-1] for s_ in seqs], beam_scores, new_src, bans, use_graphs)
+        except Exception:
+            sessions.pop(key, None)
+            if was_training:
+                model.train()
+            raise
         tv, ti = tv.tolist(), ti.tolist()
         new_seqs, new_scores, new_src = [], [], []
         for b in range(B):
