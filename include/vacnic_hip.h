@@ -95,6 +95,21 @@ typedef struct {
 } vacnic_gemv_ln_args;
 int vacnic_gemv_ln_bf16(const vacnic_gemv_ln_args* a, void* stream);
 
+/* Grouped weight gradients — nn.Linear backward w.r.t. weight and bias (autograd of MFULL:449-452 and every other Linear of
+ * the path) for SEVERAL layers in one launch:
+ *     dw[N, K] += dy[M, N]^T . x[M, K]          dbias[N] += column sums of dy   (dbias may be NULL)
+ * dy, x bf16 row-major (rows 16-byte aligned: ld % 8 == 0), dw / dbias fp32, accumulated in place.  No split-K and no atomics
+ * on dw: every output element has one writer and a fixed summation order (bitwise reproducible).  Each 1024 x 1024 block of
+ * a dw runs with its full reduction on one XCD; jobs of one call should share M (they finish together).  The torch reference
+ * runs one cuBLAS GEMM + one reduction per Linear. */
+typedef struct {
+  const void* dy; const void* x;
+  float* dw; float* dbias;
+  int64_t M, N, K;
+  int64_t lddy, ldx, lddw;
+} vacnic_wgrad_job;
+int vacnic_wgrad_group(const vacnic_wgrad_job* jobs, int64_t njobs, void* stream);
+
 /*
  * Fused attention core (replaces bmm -> +mask -> softmax -> bmm of BartAttention.forward,
  * MFULL:509-548, and nn.MultiheadAttention inside the CLIP ViT).  head_dim must be 64.
@@ -421,6 +436,21 @@ int vacnic_lmhead_ce_dlogits(const vacnic_lmhead_ce_args* a, int64_t col0, int64
 
 /* zero `bytes` bytes at `ptr` on `stream` (memset node; used for the fp32 accumulators of split-K GEMMs instead of a fill kernel) */
 int vacnic_zero_bytes(void* ptr, int64_t bytes, void* stream);
+
+/* ---- launch plans: a step's C-ABI call sequence recorded once and replayed from C++ -----------------------------------------
+ * The reference issues every kernel of a training step from Python (TRAIN:253-383); the eager path here does too (~1400 calls).
+ * Between vacnic_plan_begin() and vacnic_plan_end(h) every entry point of this library also freezes its arguments into plan h
+ * while it runs; vacnic_plan_replay(h, first, last) re-issues commands [first, last) — same kernels, same streams, same order.
+ * The caller keeps all buffers at their recorded addresses and refreshes inputs in place.  vacnic_plan_mark() (while recording)
+ * = index of the next command, for replays split around host-side work.  vacnic_stream_fence(src, dst): dst waits for all work
+ * enqueued on src so far — the recordable form of an event record + stream wait.  Handles are small integers; -1 = error. */
+int64_t vacnic_plan_begin(void);
+int vacnic_plan_end(int64_t plan);
+int64_t vacnic_plan_size(int64_t plan);
+int64_t vacnic_plan_mark(void);
+int vacnic_plan_replay(int64_t plan, int64_t first, int64_t last);
+int vacnic_plan_destroy(int64_t plan);
+int vacnic_stream_fence(void* src_stream, void* dst_stream);
 
 /* ---- hardware probes (tests only): verify MFMA / ds_read_tr lane maps assumed by the kernels -- */
 int vacnic_probe_layouts(float* out, const float* src128, int64_t n_out, void* stream);

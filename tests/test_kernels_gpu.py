@@ -169,6 +169,45 @@ def test_gemm_target_shapes_elementwise(K, M, N, K_):
     close(bsum, dy.float().sum(0), 2e-3, 2e-2 * math.sqrt(M / 256), "TT fused bias gradient")
 
 
+def test_wgrad_group_matches_torch_and_is_reproducible(K):
+    """vacnic_wgrad_group: several weight gradients dW += dY^T X (+ bias gradients) in one launch, no split-K — full-size
+    encoder shapes (d x d, 3d x d, d x 4d at M = 16384), decoder-sized reductions, ragged N / K / M, strided operands, one job
+    without a bias, accumulation into a non-zero dW, more than 16 output blocks in one call; every element against an fp32
+    product, and two runs bit-identical (one writer per element, fixed summation order)."""
+    from vacnic_amd import _lib
+    shapes = [(16384, 1024, 1024, True), (16384, 3072, 1024, True), (16384, 1024, 4096, True), (2048, 1024, 1024, True),
+              (2048, 4096, 1024, False), (1030, 520, 648, True), (1536, 1152, 2048, True)]
+    jobs, refs = [], []
+    for i, (M, N, K_, has_bias) in enumerate(shapes):
+        ldy, ldx = N + (8 if i % 2 else 0), K_ + (16 if i % 3 == 0 else 0)
+        dyb = rnd(M, ldy, scale=0.1, seed=10 + i); xb = rnd(M, ldx, seed=30 + i)
+        dy, x = dyb[:, :N], xb[:, :K_]
+        dw0 = rnd(N, K_, dtype=torch.float32, seed=50 + i)
+        db0 = rnd(N, dtype=torch.float32, seed=70 + i) if has_bias else None
+        jobs.append((dy, x, dw0, db0))
+        refs.append((dw0.clone() + dy.float().t() @ x.float(), (db0.clone() + dy.float().sum(0)) if has_bias else None, M))
+    keep = [(j[2].clone(), j[3].clone() if j[3] is not None else None) for j in jobs]
+    K.wgrad_group(jobs)
+    torch.cuda.synchronize()
+    for (dy, x, dw, db), (rw, rb, M) in zip(jobs, refs):
+        close(dw, rw, 2e-3, 2e-2 * math.sqrt(M / 256), f"dW {tuple(dw.shape)} M={M}")
+        if db is not None:
+            close(db, rb, 2e-3, 2e-2 * math.sqrt(M / 256), f"dbias {tuple(db.shape)} M={M}")
+    first = [j[2].clone() for j in jobs]
+    for j, (w0, b0) in zip(jobs, keep):
+        j[2].copy_(w0)
+        if b0 is not None:
+            j[3].copy_(b0)
+    K.wgrad_group(jobs)
+    torch.cuda.synchronize()
+    for j, f in zip(jobs, first):
+        assert torch.equal(j[2], f), "weight gradients must be bitwise reproducible"
+    # argument checks: misaligned rows are refused
+    bad = (rnd(1024, 1028, seed=1)[:, :1024], jobs[0][1][:1024], torch.zeros(1024, 1024, device="cuda"), None)
+    with pytest.raises(ValueError):
+        K.wgrad_group([bad])
+
+
 @pytest.mark.parametrize("hint", [256, 264, 256 + 64000, 256 + 16000])
 def test_gemm_persistent_many_tiles_and_ragged_rows(K, hint):
     """more tiles than CUs (the persistent work loop wraps: 65 x 5 = 325 tiles of 256x256) with a ragged last row block;

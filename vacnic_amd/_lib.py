@@ -43,6 +43,9 @@ GemvLnArgs = _struct("vacnic_gemv_ln_args", [
     ("x", vp), ("residual", vp), ("gamma", vp), ("beta", vp), ("ln_out", vp), ("w", vp), ("bias", vp), ("out", vp),
     ("M", i64), ("N", i64), ("K", i64), ("ldw", i64), ("ldo", i64), ("act", i32), ("out_mode", i32), ("eps", f32)])
 
+WgradJob = _struct("vacnic_wgrad_job", [
+    ("dy", vp), ("x", vp), ("dw", vp), ("dbias", vp), ("M", i64), ("N", i64), ("K", i64), ("lddy", i64), ("ldx", i64), ("lddw", i64)])
+
 AttnFwdArgs = _struct("vacnic_attn_fwd_args", [
     ("q", vp), ("k", vp), ("v", vp), ("out", vp), ("lse", vp), ("key_mask", vp),
     ("B", i64), ("H", i64), ("Tq", i64), ("Tk", i64),
@@ -168,9 +171,12 @@ _PLAIN_FNS = {
     "vacnic_lmhead_ce_dlogits": [C.POINTER(LmheadCeArgs), i64, i64, vp, i64, vp, vp],
     "vacnic_zero_bytes": [vp, i64, vp],
     "vacnic_beam_init": [C.POINTER(BeamState), i32, vp],
+    "vacnic_wgrad_group": [C.POINTER(WgradJob), i64, vp],
+    "vacnic_plan_end": [i64], "vacnic_plan_replay": [i64, i64, i64], "vacnic_plan_destroy": [i64], "vacnic_stream_fence": [vp, vp],
     "vacnic_beam_step": [C.POINTER(BeamState), vp, vp, i32, i32, vp],
 }
-EXPORTED = sorted(list(_STRUCT_FNS) + list(_PLAIN_FNS) + ["vacnic_last_error_string", "vacnic_version", "vacnic_decoder_step_sync_bytes", "vacnic_decoder_step_slots_bytes"])
+EXPORTED = sorted(list(_STRUCT_FNS) + list(_PLAIN_FNS) + ["vacnic_last_error_string", "vacnic_version", "vacnic_decoder_step_sync_bytes", "vacnic_decoder_step_slots_bytes",
+                                                            "vacnic_plan_begin", "vacnic_plan_size", "vacnic_plan_mark"])
 
 for _name, _st in _STRUCT_FNS.items():
     _fn = getattr(lib, _name)          # AttributeError here = stale .so: fail loudly
@@ -188,6 +194,12 @@ lib.vacnic_decoder_step_sync_bytes.restype = C.c_int64
 lib.vacnic_decoder_step_sync_bytes.argtypes = []
 lib.vacnic_decoder_step_slots_bytes.restype = C.c_int64
 lib.vacnic_decoder_step_slots_bytes.argtypes = [C.c_int64]
+lib.vacnic_plan_begin.restype = C.c_int64
+lib.vacnic_plan_begin.argtypes = []
+lib.vacnic_plan_size.restype = C.c_int64
+lib.vacnic_plan_size.argtypes = [C.c_int64]
+lib.vacnic_plan_mark.restype = C.c_int64
+lib.vacnic_plan_mark.argtypes = []
 
 _VALUE_ERRORS = (1, 2, 3)   # bad shape / dtype / alignment -> ValueError like the reference's shape checks
 

@@ -662,6 +662,7 @@ __global__ __launch_bounds__(64 * NWV) void attn_decode_kernel(AttnP p) {
 }
 
 extern "C" int vacnic_attn_fwd(const vacnic_attn_fwd_args* a, void* stream) {
+  VPLAN_REC_STRUCT(vacnic_attn_fwd, a, stream);
   VCHECK(a && a->q && a->k && a->v && a->out, VACNIC_BAD_SHAPE, "attn_fwd: null operand");
   if (int e = check_common(a->B, a->H, a->Tq, a->Tk, a->ldq, a->ldk, a->ldv, a->ldo, "attn_fwd")) return e;
   VCHECK(aligned16(a->q) && aligned16(a->k) && aligned16(a->v) && aligned16(a->out) && !(a->bsq & 7) && !(a->bsk & 7) &&
@@ -688,6 +689,7 @@ extern "C" int vacnic_attn_fwd(const vacnic_attn_fwd_args* a, void* stream) {
 }
 
 extern "C" int vacnic_attn_bwd(const vacnic_attn_bwd_args* a, void* stream) {
+  VPLAN_REC_STRUCT(vacnic_attn_bwd, a, stream);
   VCHECK(a && a->q && a->k && a->v && a->out && a->dout && a->lse && a->delta && a->dq && a->dk && a->dv,
          VACNIC_BAD_SHAPE, "attn_bwd: null operand");
   if (int e = check_common(a->B, a->H, a->Tq, a->Tk, a->ldq, a->ldk, a->ldv, a->ldo, "attn_bwd")) return e;

@@ -37,6 +37,28 @@ void vacnic_set_error(const char* fmt, ...);
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+// ---- launch plans (capi.hip): every C-ABI entry point can be RECORDED — its arguments frozen in a closure — while it runs, and
+// the recorded sequence replayed later from C++ with one call (vacnic_plan_replay): the host cost of a training step drops from
+// ~1400 Python -> ctypes round trips to one.  Entry points call VPLAN_REC / VPLAN_REC_STRUCT first; a nested entry point (one
+// C-ABI function calling another) is recorded once, by the outermost call.
+#include <functional>
+namespace vplan {
+bool active();                                   // a plan is being recorded (by this process's launching thread)
+void push(std::function<int()> f);
+extern thread_local int depth;
+struct Guard { Guard() { ++depth; } ~Guard() { --depth; } };
+inline bool outermost() { return depth == 1 && active(); }
+}  // namespace vplan
+#define VPLAN_REC(fn, ...)                                                   \
+  vplan::Guard vplan_guard__;                                               \
+  if (vplan::outermost()) vplan::push([=]() { return fn(__VA_ARGS__); })
+#define VPLAN_REC_STRUCT(fn, a, ...)                                         \
+  vplan::Guard vplan_guard__;                                               \
+  if (vplan::outermost() && (a)) {                                          \
+    auto copy__ = *(a);                                                     \
+    vplan::push([=]() { return fn(&copy__, __VA_ARGS__); });                \
+  }
+
 // ---- bf16 <-> f32 ------------------------------------------------------------------------------
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
 // f32 -> bf16, round-to-nearest-even, NaN stays NaN: ONE v_cvt_pk_bf16_f32 per two values (gfx950).  The integer

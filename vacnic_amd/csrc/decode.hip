@@ -504,6 +504,7 @@ __global__ void beam_init_kernel(int32_t* seq, float* beam_scores, int32_t* done
 extern "C" int vacnic_beam_topk(const void* logits, const float* beam_scores, const int32_t* bans, int32_t n_ban, int32_t eos,
                                 int32_t suppress_eos, int32_t forced_token, float* top_val, int32_t* top_idx, int64_t R, int64_t V,
                                 int64_t ldl, int32_t K, int32_t logits_f32, void* stream) {
+  VPLAN_REC(vacnic_beam_topk, logits, beam_scores, bans, n_ban, eos, suppress_eos, forced_token, top_val, top_idx, R, V, ldl, K, logits_f32, stream);
   VCHECK(logits && top_val && top_idx, VACNIC_BAD_SHAPE, "beam_topk: null operand");
   VCHECK(V > 0 && ldl >= V && K > 0 && K <= V, VACNIC_BAD_SHAPE, "beam_topk: bad V/ldl/K");
   if (R == 0) return VACNIC_OK;
@@ -531,6 +532,7 @@ extern "C" int vacnic_beam_topk(const void* logits, const float* beam_scores, co
 
 extern "C" int vacnic_gather_rows(const void* src, void* dst, const int64_t* idx, int64_t rows, int64_t row_bytes, int64_t row_stride_bytes,
                                   int64_t period, void* stream) {
+  VPLAN_REC(vacnic_gather_rows, src, dst, idx, rows, row_bytes, row_stride_bytes, period, stream);
   VCHECK(src && dst && idx, VACNIC_BAD_SHAPE, "gather_rows: null operand");
   if (row_stride_bytes == 0) row_stride_bytes = row_bytes;
   VCHECK((row_bytes & 15) == 0 && (row_stride_bytes & 15) == 0 && aligned16(src) && aligned16(dst), VACNIC_MISALIGNED,
@@ -548,6 +550,7 @@ extern "C" int vacnic_gather_rows(const void* src, void* dst, const int64_t* idx
 }
 
 extern "C" int vacnic_beam_init(const vacnic_beam_state* st, int32_t start_token, void* stream) {
+  VPLAN_REC_STRUCT(vacnic_beam_init, st, start_token, stream);
   VCHECK(st && st->seq[0] && st->beam_scores && st->done && st->hyp_cnt && st->hyp_worst && st->next_ids, VACNIC_BAD_SHAPE, "beam_init: null state");
   VCHECK(st->B > 0 && st->nb > 0 && st->Lmax > 0, VACNIC_BAD_SHAPE, "beam_init: bad sizes");
   const int R = (int)(st->B * st->nb);
@@ -560,6 +563,7 @@ extern "C" int vacnic_beam_init(const vacnic_beam_state* st, int32_t start_token
 
 extern "C" int vacnic_beam_step(const vacnic_beam_state* st, const float* top_val, const int32_t* top_idx, int32_t K2, int32_t cur_len,
                                 void* stream) {
+  VPLAN_REC_STRUCT(vacnic_beam_step, st, top_val, top_idx, K2, cur_len, stream);
   VCHECK(st && top_val && top_idx && st->seq[0] && st->seq[1] && st->hyp_score && st->hyp_len && st->hyp_seq && st->src_idx,
          VACNIC_BAD_SHAPE, "beam_step: null operand");
   VCHECK(st->nb >= 1 && st->nb <= 16 && K2 >= 1 && K2 <= 64 && st->nb * K2 <= 128, VACNIC_UNSUPPORTED, "beam_step: nb <= 16, K2 <= 64, nb*K2 <= 128");

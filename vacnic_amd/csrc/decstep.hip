@@ -1209,6 +1209,7 @@ extern "C" int64_t vacnic_decoder_step_sync_bytes(void) { return (int64_t)(BAR_N
 extern "C" int64_t vacnic_decoder_step_slots_bytes(int64_t L) { return (int64_t)FC1L_ARR0 + (L < 1 ? 1 : L) * (int64_t)SLOT_ARR; }
 
 extern "C" int vacnic_decoder_step(const vacnic_decoder_step_args* a, void* stream) {
+  VPLAN_REC_STRUCT(vacnic_decoder_step, a, stream);
   VCHECK(a && a->layers && a->cache && a->h0 && a->hbuf[0] && a->hbuf[1] && a->obuf && a->ctx && a->qbuf && a->fbuf && a->sync,
          VACNIC_BAD_SHAPE, "decoder_step: null operand");
   VCHECK(a->L >= 1 && a->R >= 1 && a->R <= MR, VACNIC_UNSUPPORTED, "decoder_step: 1 <= R <= 8 rows (beams x batch), L >= 1");

@@ -22,6 +22,7 @@
 // of the epilogue (output, saved pre-activation, activation-backward source, residual) is a 16-byte
 // row-contiguous access and split-K atomics are 256 contiguous bytes per wave-instruction.
 #include "gemm_kernel.h"
+#include <vector>
 
 using namespace vacgemm;
 
@@ -255,6 +256,7 @@ __global__ __launch_bounds__(64) void gemv_ln_kernel(GemvLnP p) {
 }  // namespace
 
 extern "C" int vacnic_gemv_ln_bf16(const vacnic_gemv_ln_args* a, void* stream) {
+  VPLAN_REC_STRUCT(vacnic_gemv_ln_bf16, a, stream);
   VCHECK(a && a->x && a->residual && a->gamma && a->beta && a->w && a->out, VACNIC_BAD_SHAPE, "gemv_ln: null operand");
   VCHECK(a->M >= 1 && a->M <= 8 && a->N > 0, VACNIC_UNSUPPORTED, "gemv_ln: 1 <= M <= 8 rows");
   VCHECK(a->K > 0 && (a->K & 7) == 0 && a->K <= 1024, VACNIC_UNSUPPORTED, "gemv_ln: K %% 8 == 0 and K <= 1024 (one LayerNorm row per wave)");
@@ -296,6 +298,7 @@ static double cfg_cost(const TileCfg& c, int64_t M, int64_t N, int64_t kper, int
 static int gemm_one(const vacnic_gemm_args* a, int hint, void* stream, int ce_mode = 0, int ce_col0 = 0);
 
 extern "C" int vacnic_gemm_bf16(const vacnic_gemm_args* a, void* stream) {
+  VPLAN_REC_STRUCT(vacnic_gemm_bf16, a, stream);
   VCHECK(a && a->x && a->w && a->out, VACNIC_BAD_SHAPE, "gemm: null operand");
   VCHECK(a->M > 0 && a->N > 0 && a->K > 0, VACNIC_BAD_SHAPE, "gemm: empty problem M=%ld N=%ld K=%ld",
          (long)a->M, (long)a->N, (long)a->K);
@@ -414,6 +417,58 @@ static int gemm_one(const vacnic_gemm_args* a, int tile_hint, void* stream, int 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Grouped weight gradients (nn.Linear backward w.r.t. weight and bias, MFULL:449-452, for several layers at once):
+// dw_j[N_j, K_j] += dy_j[M_j, N_j]^T x_j[M_j, K_j],  dbias_j[N_j] += column sums of dy_j.   See gemm_group_kernel.
+extern "C" int vacnic_wgrad_group(const vacnic_wgrad_job* jobs, int64_t njobs, void* stream) {
+  VCHECK(jobs && njobs > 0, VACNIC_BAD_SHAPE, "wgrad_group: no jobs");
+  vplan::Guard vplan_guard__;
+  if (vplan::outermost()) {
+    std::vector<vacnic_wgrad_job> copy__(jobs, jobs + njobs);          // the job table is host memory of the caller: freeze it
+    vplan::push([copy__, stream]() { return vacnic_wgrad_group(copy__.data(), (int64_t)copy__.size(), stream); });
+  }
+  constexpr int64_t US = (int64_t)GROUP_UT * 128;
+  GroupP g;
+  g.nunits = 0;
+  g.debug = 0;
+  {
+    static int env_debug = -1;
+    if (env_debug < 0) { const char* e = getenv("VACNIC_GEMM_DEBUG"); env_debug = e ? atoi(e) : 0; }
+    g.debug = env_debug & ~8;
+  }
+  auto flush = [&]() -> int {
+    if (g.nunits == 0) return VACNIC_OK;
+    const int e = launch_group128(g, (hipStream_t)stream);
+    g.nunits = 0;
+    return e;
+  };
+  auto span = [](int64_t rows, int64_t cols, int64_t ld) { return ((rows - 1) * ld + cols) * 2; };
+  for (int64_t j = 0; j < njobs; ++j) {
+    const vacnic_wgrad_job& a = jobs[j];
+    VCHECK(a.dy && a.x && a.dw, VACNIC_BAD_SHAPE, "wgrad_group: job %ld has a null operand", (long)j);
+    VCHECK(a.M > 0 && a.N > 0 && a.K > 0, VACNIC_BAD_SHAPE, "wgrad_group: job %ld is empty (M=%ld N=%ld K=%ld)", (long)j, (long)a.M, (long)a.N, (long)a.K);
+    VCHECK((a.lddy & 7) == 0 && (a.ldx & 7) == 0 && aligned16(a.dy) && aligned16(a.x), VACNIC_MISALIGNED,
+           "wgrad_group: job %ld: dy / x rows must be 16-byte aligned (ld %% 8 == 0)", (long)j);
+    VCHECK(a.lddy >= ((a.N + 7) & ~7LL) && a.ldx >= ((a.K + 7) & ~7LL) && a.lddw >= a.K, VACNIC_BAD_SHAPE,
+           "wgrad_group: job %ld: leading dimension too small", (long)j);
+    VCHECK((a.lddw & 3) == 0 && aligned16(a.dw), VACNIC_MISALIGNED, "wgrad_group: job %ld: dw rows must be 16-byte aligned", (long)j);
+    const int64_t xb = span(a.M, (a.N + 7) & ~7LL, a.lddy), wb = span(a.M, (a.K + 7) & ~7LL, a.ldx);
+    VCHECK(xb < 0x7ffffff0LL && wb < 0x7ffffff0LL, VACNIC_UNSUPPORTED, "wgrad_group: job %ld: operand larger than 2 GiB", (long)j);
+    for (int64_t um0 = 0; um0 < a.N; um0 += US)
+      for (int64_t un0 = 0; un0 < a.K; un0 += US) {
+        GroupUnit& u = g.u[g.nunits++];
+        u.x = (const bf16_t*)a.dy; u.w = (const bf16_t*)a.x; u.out = a.dw;
+        u.xsum = un0 == 0 ? a.dbias : nullptr;        // the bias gradient is formed by the first column block's workgroups only
+        u.M = (int)a.N; u.N = (int)a.K; u.K = (int)a.M;
+        u.ldx = (int)a.lddy; u.ldw = (int)a.ldx; u.ldo = (int)a.lddw;
+        u.um0 = (int)um0; u.un0 = (int)un0;
+        u.x_bytes = (unsigned)xb; u.w_bytes = (unsigned)wb;
+        if (g.nunits == GROUP_MAX_UNITS) { if (int e = flush()) return e; }
+      }
+  }
+  return flush();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Fused LM head + cross entropy (MFULL:1885,1997 lm_head; TRAIN:287,816 CrossEntropyLoss(ignore_index=pad)): the
 // [R, V] logits are never written.  Forward = one GEMM whose epilogue reduces every 256-column tile of a row to an
 // online-softmax pair and picks the target's logit, plus a small combine; backward recomputes the logits one vocabulary
@@ -473,6 +528,7 @@ static void fill_lmhead_gemm(vacnic_gemm_args& g, const vacnic_lmhead_ce_args* a
 }
 
 extern "C" int vacnic_lmhead_ce_fwd(const vacnic_lmhead_ce_args* a, void* stream) {
+  VPLAN_REC_STRUCT(vacnic_lmhead_ce_fwd, a, stream);
   VCHECK(a && a->h && a->emb && a->targets && a->part && a->tl && a->row_lse && a->loss_sum && a->count, VACNIC_BAD_SHAPE,
          "lmhead_ce_fwd: null operand");
   VCHECK(a->R > 0 && a->V > 0 && a->D > 0, VACNIC_BAD_SHAPE, "lmhead_ce_fwd: empty problem");
@@ -501,6 +557,7 @@ extern "C" int vacnic_lmhead_ce_fwd(const vacnic_lmhead_ce_args* a, void* stream
 
 extern "C" int vacnic_lmhead_ce_rowp(const float* row_lse, const int64_t* targets, const float* count, const float* grad_out,
                                      float grad_scale, float* rowp, int64_t R, int64_t ignore_index, void* stream) {
+  VPLAN_REC(vacnic_lmhead_ce_rowp, row_lse, targets, count, grad_out, grad_scale, rowp, R, ignore_index, stream);
   VCHECK(row_lse && targets && count && rowp && R > 0, VACNIC_BAD_SHAPE, "lmhead_ce_rowp: bad operand");
   hipLaunchKernelGGL(ce_rowp_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, (hipStream_t)stream, row_lse, targets, count,
                      grad_out, grad_scale, rowp, (int)R, ignore_index);
@@ -510,6 +567,7 @@ extern "C" int vacnic_lmhead_ce_rowp(const float* row_lse, const int64_t* target
 
 extern "C" int vacnic_lmhead_ce_dlogits(const vacnic_lmhead_ce_args* a, int64_t col0, int64_t ncols, void* dl, int64_t lddl,
                                         const float* rowp, void* stream) {
+  VPLAN_REC_STRUCT(vacnic_lmhead_ce_dlogits, a, col0, ncols, dl, lddl, rowp, stream);
   VCHECK(a && a->h && a->emb && a->targets && dl && rowp, VACNIC_BAD_SHAPE, "lmhead_ce_dlogits: null operand");
   VCHECK(col0 >= 0 && ncols > 0 && col0 + ncols <= a->V, VACNIC_BAD_SHAPE, "lmhead_ce_dlogits: chunk [%ld, +%ld) outside V=%ld",
          (long)col0, (long)ncols, (long)a->V);

@@ -236,37 +236,19 @@ __device__ __forceinline__ void wait_vm_lgkm() { asm volatile("s_waitcnt vmcnt(%
 
 // CE: compile the fused LM-head cross-entropy epilogues (out_mode 3 / 4) — their own instantiation (gemm_t256ce.hip): inside the
 // general kernels their code raised the register allocation of EVERY epilogue path (128x128 tiles: 181 -> 256 VGPRs + scratch).
-template <int BM, int BN, int WM, int WN, int BKT, int NSTAGE, bool PIPE, bool XKS, bool WKS, bool CE = false>
-__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
+// One output tile: rows [m0, m0 + BM) x columns [n0, n0 + BN), reduction slice `zsplit`.  `tn` = this tile's column index inside
+// its row panel and p.tiles_n the number of tiles that share the panel (the xsum K-steps are dealt round-robin over them).
+template <int BM, int BN, int WM, int WN, int BKT, int NSTAGE, bool PIPE, bool XKS, bool WKS, bool CE>
+__device__ __forceinline__ void gemm_tile(const GemmP& p, const int m0, const int n0, const int tn, const int zsplit) {
   constexpr int NWAVE = WM * WN, NTHR = 64 * NWAVE;
   constexpr int TM = BM / WM, TN = BN / WN;             // per-wave output sub-tile
   constexpr int FA = TM / 16, FB = TN / 16;             // MFMA tiles per wave along m / n
   constexpr int XT = BM * BKT * 2, WT = BN * BKT * 2, STAGE = XT + WT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  if (p.debug & 8) return;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave % WM, wn = wave / WM;
-
-  // XCD-aware work order.  Workgroup L of the 1-D grid runs on XCD L % 8, each with its own 4 MiB L2.
-  //  * split-K launches (weight gradients): split z = L % nsplit, so one XCD (or nsplit/8 .. 8/nsplit of them) owns a whole
-  //    K-slice and every row of dY / X in it is fetched once — all tiles of a slice run concurrently on that XCD
-  //    (+2 % on the wgrad GEMMs; with the splits in blockIdx.z every XCD touched every K-slice).
-  //  * otherwise each XCD gets a contiguous run of tiles (bijective for any tile count), n fastest so neighbours reuse the
-  //    same X panel in their L2.  (Walking 4-column strips inside a run — an 8 x 4 block of tiles in flight instead of
-  //    2 x 16 — measured no gain: the 256 MiB memory-side cache already absorbs the W re-reads.)
-  const int nt = p.tiles_m * p.tiles_n;
-  int bid = blockIdx.x, zsplit = 0;
-  if (p.split_k > 1) {
-    zsplit = bid % p.split_k;
-    bid = bid / p.split_k;
-  } else {
-    const int q = nt >> 3, r = nt & 7, xcd = bid & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int tm = bid / p.tiles_n, tn = bid - tm * p.tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
   const int kbeg = zsplit * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);
   const int ntile = (p.debug & 2) ? 0 : (kend - kbeg + BKT - 1) / BKT;
@@ -815,6 +797,87 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
 }
 
 
+template <int BM, int BN, int WM, int WN, int BKT, int NSTAGE, bool PIPE, bool XKS, bool WKS, bool CE = false>
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
+  if (p.debug & 8) return;
+  // XCD-aware work order.  Workgroup L of the 1-D grid runs on XCD L % 8, each with its own 4 MiB L2.
+  //  * split-K launches (weight gradients): split z = L % nsplit, so one XCD (or nsplit/8 .. 8/nsplit of them) owns a whole
+  //    K-slice and every row of dY / X in it is fetched once — all tiles of a slice run concurrently on that XCD
+  //    (+2 % on the wgrad GEMMs; with the splits in blockIdx.z every XCD touched every K-slice).
+  //  * otherwise each XCD gets a contiguous run of tiles (bijective for any tile count), n fastest so neighbours reuse the
+  //    same X panel in their L2.  (Walking 4-column strips inside a run — an 8 x 4 block of tiles in flight instead of
+  //    2 x 16 — measured no gain: the 256 MiB memory-side cache already absorbs the W re-reads.)
+  const int nt = p.tiles_m * p.tiles_n;
+  int bid = blockIdx.x, zsplit = 0;
+  if (p.split_k > 1) {
+    zsplit = bid % p.split_k;
+    bid = bid / p.split_k;
+  } else {
+    const int q = nt >> 3, r = nt & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tm = bid / p.tiles_n, tn = bid - tm * p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  gemm_tile<BM, BN, WM, WN, BKT, NSTAGE, PIPE, XKS, WKS, CE>(p, tm * BM, tn * BN, tn, zsplit);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Grouped weight gradients: several independent dW[N,K] += dY[M,N]^T X[M,K] problems in ONE launch, no split-K.
+// A UNIT is a block of up to UT x UT output tiles of one problem with the FULL reduction; unit u runs on XCD u % 8 (workgroup L
+// runs on XCD L % 8 and the dispatcher hands them out in order), whose 32 CUs hold all UT*UT = 64 tiles at two workgroups per
+// CU.  The tiles of a unit march through the reduction together, so every dY / X row block is fetched from HBM once and
+// re-read by its 8 consumers from that XCD's L2 — the traffic of the K-slice-per-XCD split-K mapping without its fp32
+// atomics (32 MB of memory-side atomics for a 1024 x 1024 gradient at split 8: ~25 of the launch's 60 us), and the sums are
+// bitwise reproducible: every output element has ONE writer and a fixed summation order.
+constexpr int GROUP_UT = 8;                 // tiles per unit side (128-wide tiles: 1024 x 1024 outputs per unit)
+constexpr int GROUP_MAX_UNITS = 16;
+struct GroupUnit {
+  const bf16_t* x; const bf16_t* w; float* out; float* xsum;
+  int M, N, K, ldx, ldw, ldo;
+  int um0, un0;                             // first output row / column of the unit
+  unsigned x_bytes, w_bytes;
+};
+struct GroupP { GroupUnit u[GROUP_MAX_UNITS]; int nunits; int debug; };
+
+template <int BM, int BN, int WM, int WN, int BKT, int NSTAGE, bool PIPE>
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_group_kernel(GroupP g) {
+  constexpr int TPU = GROUP_UT * GROUP_UT;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int unit = (j / TPU) * 8 + xcd;
+  if (unit >= g.nunits) return;
+  const int t = j % TPU;
+  const int tm = t / GROUP_UT, tn = t % GROUP_UT;
+  const GroupUnit& u = g.u[unit];
+  const int m0 = u.um0 + tm * BM, n0 = u.un0 + tn * BN;
+  if (m0 >= u.M || n0 >= u.N) return;
+  GemmP p;
+  p.x = u.x; p.w = u.w; p.bias = nullptr; p.out = u.out; p.preact = nullptr; p.dact_src = nullptr; p.residual = nullptr;
+  p.xsum = u.xsum;
+  p.M = u.M; p.N = u.N; p.K = u.K; p.ldx = u.ldx; p.ldw = u.ldw; p.ldo = u.ldo;
+  p.act = VACNIC_ACT_NONE; p.out_mode = 2; p.split_k = 1; p.k_per_split = (u.K + BK - 1) / BK * BK;
+  p.alpha = 1.0f; p.x_bytes = u.x_bytes; p.w_bytes = u.w_bytes;
+  p.tiles_m = GROUP_UT; p.tiles_n = min(GROUP_UT, (u.N - u.un0 + BN - 1) / BN);
+  p.ce_col0 = 0; p.debug = g.debug;
+  gemm_tile<BM, BN, WM, WN, BKT, NSTAGE, PIPE, true, true, false>(p, m0, n0, tn, 0);
+}
+
+template <int BM, int BN, int WM, int WN, int BKT, int NSTAGE, bool PIPE>
+int launch_gemm_group(const GroupP& g, hipStream_t s) {
+  static_assert(BM == 128 && BN == 128, "units are GROUP_UT x GROUP_UT tiles of 128 x 128");
+  const int rounds = (g.nunits + 7) / 8;
+  dim3 grid(rounds * 8 * GROUP_UT * GROUP_UT), block(64 * WM * WN);
+  constexpr size_t lds = NSTAGE * (BM + BN) * BKT * 2;
+  auto kern = gemm_group_kernel<BM, BN, WM, WN, BKT, NSTAGE, PIPE>;
+  if (lds > 65536) {
+    static bool once = false;
+    if (!once) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
+  }
+  hipLaunchKernelGGL(kern, grid, block, lds, s, g);
+  VLAUNCH_CHECK();
+  return VACNIC_OK;
+}
+
+
 template <int BM, int BN, int WM, int WN, int BKT, int NSTAGE, bool PIPE = false, bool CE = false>
 int launch_gemm(const GemmP& p0, bool xks, bool wks, int zsplits, hipStream_t s) {
   GemmP p = p0;
@@ -856,5 +919,6 @@ int launch_t260(const GemmP& p, bool xks, bool wks, int zsplits, hipStream_t s);
 int launch_t261(const GemmP& p, bool xks, bool wks, int zsplits, hipStream_t s);
 int launch_t262(const GemmP& p, bool xks, bool wks, int zsplits, hipStream_t s);
 int launch_t256ce(const GemmP& p, bool xks, bool wks, int zsplits, hipStream_t s); // 256x256 ping-pong + LM-head cross-entropy epilogues
+int launch_group128(const GroupP& g, hipStream_t s);                                // grouped weight gradients, 128x128 tiles (gemm_tgroup.hip)
 
 }  // namespace vacgemm

@@ -395,6 +395,7 @@ __global__ __launch_bounds__(256) void secla_dfaces_kernel(const float* __restri
 }  // namespace
 
 extern "C" int vacnic_ce_fwd(const vacnic_ce_args* a, void* stream) {
+  VPLAN_REC_STRUCT(vacnic_ce_fwd, a, stream);
   VCHECK(a && a->logits && a->targets && a->row_lse && a->loss_sum && a->count, VACNIC_BAD_SHAPE, "ce_fwd: null operand");
   VCHECK(a->V > 0 && a->ldl >= a->V, VACNIC_BAD_SHAPE, "ce_fwd: bad V/ldl");
   if (a->R == 0) return VACNIC_OK;
@@ -411,6 +412,7 @@ extern "C" int vacnic_ce_fwd(const vacnic_ce_args* a, void* stream) {
 }
 
 extern "C" int vacnic_ce_bwd(const vacnic_ce_args* a, void* stream) {
+  VPLAN_REC_STRUCT(vacnic_ce_bwd, a, stream);
   VCHECK(a && a->logits && a->targets && a->row_lse && a->count && a->dlogits, VACNIC_BAD_SHAPE, "ce_bwd: null operand");
   VCHECK(a->V > 0 && a->ldl >= a->V && a->ldd >= a->V, VACNIC_BAD_SHAPE, "ce_bwd: bad V/ldl/ldd");
   if (a->R == 0) return VACNIC_OK;
@@ -429,6 +431,7 @@ extern "C" int vacnic_ce_bwd(const vacnic_ce_args* a, void* stream) {
 
 extern "C" int vacnic_combine_losses(const float* ce_sum, const float* count, const float* secla, const float* colam,
                                      float w_secla, float w_colam, float* out4, void* stream) {
+  VPLAN_REC(vacnic_combine_losses, ce_sum, count, secla, colam, w_secla, w_colam, out4, stream);
   VCHECK(ce_sum && count && out4, VACNIC_BAD_SHAPE, "combine_losses: null operand");
   hipLaunchKernelGGL(combine_losses_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ce_sum, count, secla, colam,
                      w_secla, w_colam, out4);
@@ -437,6 +440,7 @@ extern "C" int vacnic_combine_losses(const float* ce_sum, const float* count, co
 }
 
 extern "C" int vacnic_colam_fwd(const vacnic_colam_fwd_args* a, void* stream) {
+  VPLAN_REC_STRUCT(vacnic_colam_fwd, a, stream);
   VCHECK(a && a->hs && a->hg && a->mask && a->loss && a->cos && a->pooled_s && a->pooled_g, VACNIC_BAD_SHAPE, "colam_fwd: null operand");
   VCHECK(a->B > 0 && a->T > 0 && a->D > 0, VACNIC_BAD_SHAPE, "colam_fwd: empty");
   VCHECK(a->T <= 1024 && (a->D & 7) == 0 && aligned16(a->hs) && aligned16(a->hg), VACNIC_BAD_SHAPE, "colam_fwd: needs T <= 1024, D %% 8 == 0, 16-byte aligned states");
@@ -450,6 +454,7 @@ extern "C" int vacnic_colam_fwd(const vacnic_colam_fwd_args* a, void* stream) {
 }
 
 extern "C" int vacnic_colam_bwd(const vacnic_colam_bwd_args* a, void* stream) {
+  VPLAN_REC_STRUCT(vacnic_colam_bwd, a, stream);
   VCHECK(a && a->cos && a->pooled_s && a->pooled_g && a->mask && a->dhs, VACNIC_BAD_SHAPE, "colam_bwd: null operand");
   hipLaunchKernelGGL(colam_bwd_kernel, dim3((unsigned)a->B), dim3(256), 0, (hipStream_t)stream, a->cos, a->pooled_s,
                      a->pooled_g, a->mask, (bf16_t*)a->dhs, (int)a->B, (int)a->T, (int)a->D, a->margin, a->grad_out,
@@ -459,6 +464,7 @@ extern "C" int vacnic_colam_bwd(const vacnic_colam_bwd_args* a, void* stream) {
 }
 
 extern "C" int vacnic_secla_fwd(const vacnic_secla_fwd_args* a, void* stream) {
+  VPLAN_REC_STRUCT(vacnic_secla_fwd, a, stream);
   VCHECK(a && a->faces && a->names && a->sim && a->logits1 && a->logits2 && a->loss, VACNIC_BAD_SHAPE, "secla_fwd: null operand");
   VCHECK(a->B > 0 && a->F > 0 && a->N > 0 && a->D > 0, VACNIC_BAD_SHAPE, "secla_fwd: empty");
   VCHECK((a->D & 7) == 0 && aligned16(a->faces) && aligned16(a->names), VACNIC_BAD_SHAPE, "secla_fwd: needs D %% 8 == 0 and 16-byte aligned faces / names");
@@ -474,6 +480,7 @@ extern "C" int vacnic_secla_fwd(const vacnic_secla_fwd_args* a, void* stream) {
 }
 
 extern "C" int vacnic_secla_bwd(const vacnic_secla_bwd_args* a, void* stream) {
+  VPLAN_REC_STRUCT(vacnic_secla_bwd, a, stream);
   VCHECK(a && a->names && a->sim && a->logits1 && a->logits2 && a->dfaces && a->wsim, VACNIC_BAD_SHAPE, "secla_bwd: null operand");
   hipStream_t s = (hipStream_t)stream;
   const int B = (int)a->B, F = (int)a->F, N = (int)a->N, D = (int)a->D;

@@ -175,6 +175,7 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const bf16_t* __restrict
 
 extern "C" int vacnic_copy3d_bf16(const void* src, void* dst, int64_t B, int64_t rows, int64_t cols, int64_t lds,
                                   int64_t ldd, int64_t bss, int64_t bsd, int32_t accumulate, void* stream) {
+  VPLAN_REC(vacnic_copy3d_bf16, src, dst, B, rows, cols, lds, ldd, bss, bsd, accumulate, stream);
   VCHECK(src && dst, VACNIC_BAD_SHAPE, "copy3d: null operand");
   VCHECK((cols & 7) == 0 && (lds & 7) == 0 && (ldd & 7) == 0 && (bss & 7) == 0 && (bsd & 7) == 0 && aligned16(src) && aligned16(dst),
          VACNIC_MISALIGNED, "copy3d: cols/strides must be multiples of 8 and pointers 16-byte aligned");
@@ -187,9 +188,11 @@ extern "C" int vacnic_copy3d_bf16(const void* src, void* dst, int64_t B, int64_t
 }
 extern "C" int vacnic_copy2d_bf16(const void* src, void* dst, int64_t rows, int64_t cols, int64_t lds, int64_t ldd,
                                   int32_t accumulate, void* stream) {
+  VPLAN_REC(vacnic_copy2d_bf16, src, dst, rows, cols, lds, ldd, accumulate, stream);
   return vacnic_copy3d_bf16(src, dst, 1, rows, cols, lds, ldd, 0, 0, accumulate, stream);
 }
 extern "C" int vacnic_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream) {
+  VPLAN_REC(vacnic_add_bf16, a, b, out, n, stream);
   VCHECK(a && b && out, VACNIC_BAD_SHAPE, "add: null operand");
   VCHECK((n & 7) == 0 && aligned16(a) && aligned16(b) && aligned16(out), VACNIC_MISALIGNED, "add: n must be a multiple of 8, pointers 16-byte aligned");
   if (n == 0) return VACNIC_OK;
@@ -199,6 +202,7 @@ extern "C" int vacnic_add_bf16(const void* a, const void* b, void* out, int64_t 
   return VACNIC_OK;
 }
 extern "C" int vacnic_pad_cols_bf16(const void* src, void* dst, int64_t R, int64_t C, int64_t Cp, int64_t lds, void* stream) {
+  VPLAN_REC(vacnic_pad_cols_bf16, src, dst, R, C, Cp, lds, stream);
   VCHECK(src && dst && Cp >= C && lds >= C, VACNIC_BAD_SHAPE, "pad_cols: bad operand");
   if (R * Cp == 0) return VACNIC_OK;
   hipLaunchKernelGGL(pad_cols_kernel, dim3(grid_for(R * Cp)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src,
@@ -208,6 +212,7 @@ extern "C" int vacnic_pad_cols_bf16(const void* src, void* dst, int64_t R, int64
 }
 extern "C" int vacnic_im2col_patches(const float* img, void* patches, int64_t B, int64_t HW, int64_t patch, int64_t Kp,
                                      void* stream) {
+  VPLAN_REC(vacnic_im2col_patches, img, patches, B, HW, patch, Kp, stream);
   VCHECK(img && patches, VACNIC_BAD_SHAPE, "im2col: null operand");
   VCHECK(patch > 0 && HW % patch == 0 && Kp >= 3 * patch * patch, VACNIC_BAD_SHAPE, "im2col: bad geometry");
   const long g = HW / patch;
@@ -218,6 +223,7 @@ extern "C" int vacnic_im2col_patches(const float* img, void* patches, int64_t B,
 }
 extern "C" int vacnic_vit_assemble(const void* patch_emb, const void* cls, const void* pos, void* out, int64_t B,
                                    int64_t G2, int64_t W, void* stream) {
+  VPLAN_REC(vacnic_vit_assemble, patch_emb, cls, pos, out, B, G2, W, stream);
   VCHECK(patch_emb && cls && pos && out, VACNIC_BAD_SHAPE, "vit_assemble: null operand");
   hipLaunchKernelGGL(vit_assemble_kernel, dim3(grid_for(B * (G2 + 1) * W)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)patch_emb, (const bf16_t*)cls, (const bf16_t*)pos, (bf16_t*)out, (long)B, (int)G2, (int)W);
@@ -226,6 +232,7 @@ extern "C" int vacnic_vit_assemble(const void* patch_emb, const void* cls, const
 }
 extern "C" int vacnic_prep_ids(const int64_t* ids, uint8_t* mask, int64_t* shifted, int64_t B, int64_t T, int64_t pad_id,
                                int64_t start_id, void* stream) {
+  VPLAN_REC(vacnic_prep_ids, ids, mask, shifted, B, T, pad_id, start_id, stream);
   VCHECK(ids, VACNIC_BAD_SHAPE, "prep_ids: null ids");
   if (B * T == 0) return VACNIC_OK;
   hipLaunchKernelGGL(prep_ids_kernel, dim3(grid_for(B * T)), dim3(256), 0, (hipStream_t)stream, ids, mask, shifted,
@@ -234,6 +241,7 @@ extern "C" int vacnic_prep_ids(const int64_t* ids, uint8_t* mask, int64_t* shift
   return VACNIC_OK;
 }
 extern "C" int vacnic_face_mask(const float* faces, uint8_t* mask, int64_t BF, int64_t D, void* stream) {
+  VPLAN_REC(vacnic_face_mask, faces, mask, BF, D, stream);
   VCHECK(faces && mask, VACNIC_BAD_SHAPE, "face_mask: null operand");
   if (BF == 0) return VACNIC_OK;
   hipLaunchKernelGGL(face_mask_kernel, dim3((unsigned)((BF + 255) / 256)), dim3(256), 0, (hipStream_t)stream, faces, mask,
@@ -243,6 +251,7 @@ extern "C" int vacnic_face_mask(const float* faces, uint8_t* mask, int64_t BF, i
 }
 extern "C" int vacnic_argmax_rows(const void* logits, int64_t* out, int64_t R, int64_t V, int64_t ldl, int32_t logits_f32,
                                   void* stream) {
+  VPLAN_REC(vacnic_argmax_rows, logits, out, R, V, ldl, logits_f32, stream);
   VCHECK(logits && out && V > 0, VACNIC_BAD_SHAPE, "argmax: bad operand");
   if (R == 0) return VACNIC_OK;
   if (logits_f32) hipLaunchKernelGGL(argmax_kernel<true>, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, logits, out, (int)V, (long)ldl);
@@ -251,6 +260,7 @@ extern "C" int vacnic_argmax_rows(const void* logits, int64_t* out, int64_t R, i
   return VACNIC_OK;
 }
 extern "C" int vacnic_bias_grad(const void* dy, float* dbias, int64_t M, int64_t N, int64_t ldy, void* stream) {
+  VPLAN_REC(vacnic_bias_grad, dy, dbias, M, N, ldy, stream);
   VCHECK(dy && dbias, VACNIC_BAD_SHAPE, "bias_grad: null operand");
   VCHECK((ldy & 7) == 0 && aligned16(dy), VACNIC_MISALIGNED, "bias_grad: dy rows must be 16-byte aligned");
   if (M == 0 || N == 0) return VACNIC_OK;
@@ -293,6 +303,7 @@ __global__ __launch_bounds__(256) void image_u8_normalize_kernel(const uint8_t* 
 
 extern "C" int vacnic_image_u8_normalize(const uint8_t* src, const uint8_t* flip, float* dst, int64_t B, int64_t H, int64_t W,
                                          float mean0, float mean1, float mean2, float std0, float std1, float std2, void* stream) {
+  VPLAN_REC(vacnic_image_u8_normalize, src, flip, dst, B, H, W, mean0, mean1, mean2, std0, std1, std2, stream);
   VCHECK(src && dst, VACNIC_BAD_SHAPE, "image_u8_normalize: null operand");
   VCHECK(B >= 0 && H > 0 && W > 0 && std0 != 0.f && std1 != 0.f && std2 != 0.f, VACNIC_BAD_SHAPE, "image_u8_normalize: bad shape / zero std");
   const long total = B * 3 * H * W;
@@ -307,6 +318,7 @@ extern "C" int vacnic_image_u8_normalize(const uint8_t* src, const uint8_t* flip
 
 // zero-fill on the caller's stream (a memset node: graph-capturable, no kernel) — the fp32 accumulators of split-K GEMMs
 extern "C" int vacnic_zero_bytes(void* ptr, int64_t bytes, void* stream) {
+  VPLAN_REC(vacnic_zero_bytes, ptr, bytes, stream);
   VCHECK(ptr && bytes >= 0, VACNIC_BAD_SHAPE, "zero_bytes: bad operand");
   if (bytes == 0) return VACNIC_OK;
   if (hipMemsetAsync(ptr, 0, (size_t)bytes, (hipStream_t)stream) != hipSuccess) {

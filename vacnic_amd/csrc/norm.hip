@@ -471,6 +471,7 @@ static int check_d(int64_t D, const char* who) {
 }
 
 extern "C" int vacnic_add_ln_fwd(const vacnic_add_ln_fwd_args* a, void* stream) {
+  VPLAN_REC_STRUCT(vacnic_add_ln_fwd, a, stream);
   VCHECK(a && a->x && a->gamma && a->beta && a->out, VACNIC_BAD_SHAPE, "add_ln_fwd: null operand");
   if (int e = check_d(a->D, "add_ln_fwd")) return e;
   if (a->R == 0) return VACNIC_OK;
@@ -517,6 +518,7 @@ __global__ __launch_bounds__(256) void ln_partial_reduce_kernel(const float* __r
 }
 
 extern "C" int vacnic_add_ln_bwd(const vacnic_add_ln_bwd_args* a, void* stream) {
+  VPLAN_REC_STRUCT(vacnic_add_ln_bwd, a, stream);
   VCHECK(a && a->dout && a->x && a->gamma && a->mean && a->rstd, VACNIC_BAD_SHAPE, "add_ln_bwd: null operand");
   if (int e = check_d(a->D, "add_ln_bwd")) return e;
   if (a->R == 0) return VACNIC_OK;
@@ -552,6 +554,7 @@ extern "C" int vacnic_add_ln_bwd(const vacnic_add_ln_bwd_args* a, void* stream) 
 }
 
 extern "C" int vacnic_embed_ln_fwd(const vacnic_embed_ln_fwd_args* a, void* stream) {
+  VPLAN_REC_STRUCT(vacnic_embed_ln_fwd, a, stream);
   VCHECK(a && a->ids && a->embed && a->pos && a->gamma && a->beta && a->out, VACNIC_BAD_SHAPE, "embed_ln_fwd: null operand");
   if (int e = check_d(a->D, "embed_ln_fwd")) return e;
   const int64_t R = a->B * a->T;
@@ -565,6 +568,7 @@ extern "C" int vacnic_embed_ln_fwd(const vacnic_embed_ln_fwd_args* a, void* stre
 }
 
 extern "C" int vacnic_embed_ln_bwd(const vacnic_embed_ln_bwd_args* a, void* stream) {
+  VPLAN_REC_STRUCT(vacnic_embed_ln_bwd, a, stream);
   VCHECK(a && a->ids && a->embed && a->pos && a->dout && a->gamma && a->mean && a->rstd, VACNIC_BAD_SHAPE,
          "embed_ln_bwd: null operand");
   if (int e = check_d(a->D, "embed_ln_bwd")) return e;
@@ -582,6 +586,7 @@ extern "C" int vacnic_embed_ln_bwd(const vacnic_embed_ln_bwd_args* a, void* stre
 }
 
 extern "C" int vacnic_name_embed_mean(const vacnic_name_embed_args* a, void* stream) {
+  VPLAN_REC_STRUCT(vacnic_name_embed_mean, a, stream);
   VCHECK(a && a->ids && a->embed && a->pos && a->gamma && a->beta && a->out, VACNIC_BAD_SHAPE, "name_embed: null operand");
   if (int e = check_d(a->D, "name_embed")) return e;
   const int64_t R = a->B * a->Nn;

@@ -117,6 +117,7 @@ inline unsigned grid_for(long work) {
 }  // namespace
 
 extern "C" int vacnic_lr_step(float* hyper, float base_lr, float warmup_steps, float total_steps, uint64_t* rng_counter, void* stream) {
+  VPLAN_REC(vacnic_lr_step, hyper, base_lr, warmup_steps, total_steps, rng_counter, stream);
   VCHECK(hyper, VACNIC_BAD_SHAPE, "lr_step: null hyper");
   hipLaunchKernelGGL(lr_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, hyper, base_lr, warmup_steps, total_steps, (unsigned long long*)rng_counter);
   VLAUNCH_CHECK();
@@ -124,6 +125,7 @@ extern "C" int vacnic_lr_step(float* hyper, float base_lr, float warmup_steps, f
 }
 
 extern "C" int vacnic_adamw(const vacnic_adamw_args* a, void* stream) {
+  VPLAN_REC_STRUCT(vacnic_adamw, a, stream);
   VCHECK(a && a->p && a->g && a->m && a->v && a->hyper, VACNIC_BAD_SHAPE, "adamw: null operand");
   VCHECK((a->n & 3) == 0, VACNIC_BAD_SHAPE, "adamw: n=%ld must be a multiple of 4 (pad the arena)", (long)a->n);
   VCHECK(aligned16(a->p) && aligned16(a->g) && aligned16(a->m) && aligned16(a->v) && (!a->p_bf16 || (((uintptr_t)a->p_bf16) & 7) == 0),
@@ -143,6 +145,7 @@ extern "C" int vacnic_adamw(const vacnic_adamw_args* a, void* stream) {
 
 extern "C" int vacnic_grad_clip_coef(const float* g, int64_t n, float grad_scale, float max_norm, float* partials,
                                      float* out, void* stream) {
+  VPLAN_REC(vacnic_grad_clip_coef, g, n, grad_scale, max_norm, partials, out, stream);
   VCHECK(g && partials && out, VACNIC_BAD_SHAPE, "grad_clip_coef: null operand");
   VCHECK((n & 3) == 0 && aligned16(g), VACNIC_BAD_SHAPE, "grad_clip_coef: arena must be 16-byte aligned, n=%ld a multiple of 4", (long)n);
   VCHECK(max_norm > 0.f, VACNIC_BAD_SHAPE, "grad_clip_coef: max_norm must be > 0");
@@ -154,6 +157,7 @@ extern "C" int vacnic_grad_clip_coef(const float* g, int64_t n, float grad_scale
 }
 
 extern "C" int vacnic_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream) {
+  VPLAN_REC(vacnic_cast_f32_bf16, src, dst, n, stream);
   VCHECK(src && dst, VACNIC_BAD_SHAPE, "cast: null operand");
   VCHECK(aligned16(src) && (((uintptr_t)dst) & 7) == 0, VACNIC_MISALIGNED, "cast_f32_bf16: misaligned");
   if (n == 0) return VACNIC_OK;
@@ -162,6 +166,7 @@ extern "C" int vacnic_cast_f32_bf16(const float* src, void* dst, int64_t n, void
   return VACNIC_OK;
 }
 extern "C" int vacnic_cast_bf16_f32(const void* src, float* dst, int64_t n, void* stream) {
+  VPLAN_REC(vacnic_cast_bf16_f32, src, dst, n, stream);
   VCHECK(src && dst, VACNIC_BAD_SHAPE, "cast: null operand");
   if (n == 0) return VACNIC_OK;
   hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, dst, (long)n);

@@ -73,6 +73,7 @@ __global__ __launch_bounds__(64) void probe_kernel(float* out, const float* oob_
 }  // namespace
 
 extern "C" int vacnic_probe_layouts(float* out, const float* src128, int64_t n_out, void* stream) {
+  VPLAN_REC(vacnic_probe_layouts, out, src128, n_out, stream);
   VCHECK(out && src128 && n_out >= 2624, VACNIC_BAD_SHAPE, "probe: need >= 2624 output floats and a 128-float source");
   hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out, src128);
   VLAUNCH_CHECK();

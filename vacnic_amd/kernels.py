@@ -127,6 +127,20 @@ def wgrad_split(M_red, n_tiles):
     return s
 
 
+def wgrad_group(jobs):
+    """jobs: list of (dy2d [M,N] bf16, x2d [M,K] bf16, dw [N,K] f32 view, dbias [N] f32 or None): dw += dy^T x, dbias += colsum(dy)
+    for all of them in one launch per 16 output blocks of 1024 x 1024 — no split-K, no atomics on dw (vacnic_wgrad_group)."""
+    arr = (_lib.WgradJob * len(jobs))()
+    for j, (dy, x, dw, db) in enumerate(jobs):
+        M, N = dy.shape
+        Kd = x.shape[1]
+        assert x.shape[0] == M and tuple(dw.shape) == (N, Kd) and dy.stride(1) == 1 and x.stride(1) == 1 and dw.stride(1) == 1
+        a = arr[j]
+        a.dy, a.x, a.dw, a.dbias = _p(dy), _p(x), _p(dw), _p(db)
+        a.M, a.N, a.K, a.lddy, a.ldx, a.lddw = M, N, Kd, dy.stride(0), x.stride(0), dw.stride(0)
+    call("vacnic_wgrad_group", arr, len(jobs), _stream())
+
+
 # ------------------------------------------------------------------------------------------- attention
 def attn_fwd(q, k, v, B, H, Tq, Tk, key_mask=None, causal=False, scale=0.125, need_lse=True):
     """q/k/v: [B, T, >=H*64] views (unit inner stride); returns out [B,Tq,H*64] bf16 and lse [B,H,Tq]."""

@@ -61,15 +61,105 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+# ---- grouped weight gradients -------------------------------------------------------------------------------------------
+# A weight gradient with a long reduction (M = B*S rows) and a small output (d x d .. 4d x d) cannot fill 256 CUs without
+# split-K, and split-K sums through fp32 atomics (32 MB of them for one 1024 x 1024 gradient: ~25 of its 60 us).  Weight
+# gradients are needed only by AdamW / the DDP reducer, so they are DEFERRED: jobs queue up during backward and leave in groups
+# of WGRAD_GROUP_UNITS output blocks of 1024 x 1024, each block with its full reduction on one XCD (vacnic_wgrad_group): no
+# atomics on dW, bitwise reproducible sums, a quarter of the launches.  The queue empties at the end of backward (autograd
+# engine callback).  VACNIC_WGRAD_GROUP=0 restores one split-K GEMM per Linear.
+WGRAD_GROUP = __import__("os").environ.get("VACNIC_WGRAD_GROUP", "1") != "0"
+WGRAD_GROUP_UNITS = 16
+WGRAD_GROUP_MIN_M = 1024
+
+
+class _WgradQueue:
+    def __init__(self):
+        self.by_m = {}            # reduction length -> [(dy2d, x2d, spec)]
+        self.units = {}
+        self.dst = set()          # gradient views with a queued job (a second writer of the same view must not share a launch)
+        self.armed = False
+
+    def add(self, dy2d, x2d, spec, M):
+        if spec.wgrad.data_ptr() in self.dst:          # tied weights (--init_attn_weight): serialise the writers
+            self.flush()
+        if not self.armed:
+            # the engine runs this once, after the last node of the CURRENT backward pass
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+                self.armed = True
+            except RuntimeError:                       # not inside a backward pass (a direct call): nothing will flush later
+                self.by_m.setdefault(M, []).append((dy2d, x2d, spec))
+                self._launch(M)
+                return
+        self.dst.add(spec.wgrad.data_ptr())
+        self.by_m.setdefault(M, []).append((dy2d, x2d, spec))
+        u = self.units[M] = self.units.get(M, 0) + ((spec.N + 1023) // 1024) * ((spec.K + 1023) // 1024)
+        if u >= WGRAD_GROUP_UNITS:
+            self._launch(M)
+
+    def _launch(self, M):
+        jobs = self.by_m.pop(M, [])
+        self.units.pop(M, None)
+        if not jobs:
+            return
+        for _, _, sp in jobs:
+            self.dst.discard(sp.wgrad.data_ptr())
+        packed = [(dy, x, sp.wgrad, sp.bgrad) for dy, x, sp in jobs]
+        side = streams.wgrad_stream()
+        if side is None:
+            K.wgrad_group(packed)
+            for _, _, sp in jobs:
+                ddp.done(sp.wgrad, sp.bgrad)
+            return
+        # (the side stream already waits for every queued job's producer: add() is called behind side.wait_stream(producer))
+        if ddp.TRACKER is None:
+            with K.launch_on(streams.wgrad_raw()):
+                K.wgrad_group(packed)
+        else:
+            with torch.cuda.stream(side):
+                K.wgrad_group(packed)
+                for _, _, sp in jobs:
+                    ddp.done(sp.wgrad, sp.bgrad)
+        for dy, x, _ in jobs:
+            streams.keep(dy, x)
+
+    def flush(self):
+        self.armed = False
+        for M in list(self.by_m):
+            self._launch(M)
+
+
+_WGQ = _WgradQueue()
+
+
+def flush_wgrads():
+    """launch every deferred weight gradient now (the autograd engine does this at the end of backward)."""
+    _WGQ.flush()
+
+
+def _groupable(dy2d, x2d, spec, M):
+    return (WGRAD_GROUP and spec.wgrad is not None and not _NO_XSUM and M >= WGRAD_GROUP_MIN_M and spec.N >= 512 and spec.K >= 512
+            and dy2d.stride(0) % 8 == 0 and x2d.stride(0) % 8 == 0 and spec.wgrad.stride(0) % 4 == 0
+            and dy2d.shape[1] == spec.N and x2d.shape[1] == spec.K)
+
+
 def _wgrad(dy2d, x2d, spec, M):
     """spec.wgrad[N,K] += dy^T x ; spec.bgrad[N] += colsum(dy).  Off the critical path: issued on the weight-gradient
     side stream when streams are enabled (each weight has exactly one writer op, so there is no cross-stream race)."""
     side = streams.wgrad_stream()
+    group = _groupable(dy2d, x2d, spec, M)
     if side is None:
+        if group:
+            _WGQ.add(dy2d, x2d, spec, M)
+            return
         _wgrad_impl(dy2d, x2d, spec, M)
         ddp.done(spec.wgrad, spec.bgrad)
         return
     side.wait_stream(torch.cuda.current_stream())          # dy / x were produced on the compute stream
+    if group:
+        _WGQ.add(dy2d, x2d, spec, M)
+        return
     if ddp.TRACKER is None:
         with K.launch_on(streams.wgrad_raw()):
             _wgrad_impl(dy2d, x2d, spec, M)
