@@ -76,10 +76,21 @@ class GemmTimer:
             timer.rec.append((kind, 2.0 * M * N * Kd, s, e, (M, N, Kd)))
             return out
         K.gemm = timed
+        self.orig_group = K.wgrad_group
+
+        def timed_group(jobs):
+            s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+            s.record()
+            timer.orig_group(jobs)
+            e.record()
+            fl = sum(2.0 * dy.shape[0] * dy.shape[1] * x.shape[1] for dy, x, _, _ in jobs)
+            timer.rec.append(("TT", fl, s, e, (len(jobs), -1, int(jobs[0][0].shape[0]))))
+        K.wgrad_group = timed_group
 
     def remove(self):
         from vacnic_amd import kernels as K
         K.gemm = self.orig
+        K.wgrad_group = self.orig_group
 
     def summary(self):
         agg = {}
@@ -225,9 +236,9 @@ def config5_id_check(model, cfg, margin=40.0):
     """Id check of configs[4]'s code path at FULL model size (12+12 layers, S=512): the persistent decoder-step kernel (R = 5
     rows) against the kernel-per-op chain (VACNIC_DECODE_PER_OP=1), beam 5 / max_length 50 / length_penalty 2.0 / min_length 49.
     A random-init model's next-token distribution is flat (top-2 margins below bf16 resolution), so two correct bf16
-    implementations need not agree on ids.  Like tests/golden's config-5 fixture (oracle/cfg5_fixture.py, same recipe and weight
-    scales) the check therefore conditions the model first — temporarily, everything is restored afterwards: tied embedding x6,
-    decoder fc2 x8 / attention value+out projections x1.5, and ONE planted 48-token caption (each chain token's embedding row
+    implementations need not agree on ids.  Like tests/golden's config-5 fixture (oracle/cfg5_fixture.py, same recipe) the check
+    therefore conditions the model first — temporarily, everything is restored afterwards: tied embedding x6, decoder fc2 x3,
+    and ONE planted 48-token caption (each chain token's embedding row
     gets a component along the final hidden state that precedes it, sized to win by `margin` logit units; states from the
     per-op decoder, teacher forced, a few rounds until the margins hold) — then runs both paths.
     Returns {"ids_match_per_op", "ids_match_planted", "planted_margin_min", ...}."""
@@ -236,10 +247,11 @@ def config5_id_check(model, cfg, margin=40.0):
     from vacnic_amd.models.clip_vit import extract_clip_img_feat
     b, mask, nmask = _config5_inputs(cfg, 4242, 0)
     shared = model.model.shared.weight
-    scaled = [(shared, 6.0)]
-    for layer in model.model.decoder.layers:
-        scaled += [(layer.fc2.weight, 8.0)] + [(w, 1.5) for w in (layer.encoder_attn.v_proj.weight, layer.encoder_attn.out_proj.weight,
-                                                                  layer.self_attn.v_proj.weight, layer.self_attn.out_proj.weight)]
+    # 12 decoder layers dilute the input token's share of the final state by themselves; fc2 x3 removes what is left of it
+    # (self-similarity 0.26 -> 0.00) without making the network a noise amplifier: measured with the oracle on a 12-layer decoder,
+    # bf16 rounding moves the token-specific part of the final state by 2.8 % (attention value/out scales of 1.5, which the 2-layer
+    # fixture uses, make that 12-27 % at this depth — two correct bf16 decoders then disagree on everything)
+    scaled = [(shared, 6.0)] + [(layer.fc2.weight, 3.0) for layer in model.model.decoder.layers]
     saved = [p_.data.clone() for p_, _ in scaled]
     chain = [2] + [int(t) for t in np.random.default_rng(7).permutation(np.arange(1000, 50000))[:48]]
     out = {"ids_match_per_op": None}
@@ -276,9 +288,10 @@ def config5_id_check(model, cfg, margin=40.0):
                 return torch.stack(hs), worst
             mu = sweep(False, None)[0].mean(0)        # the direction all final states share (see oracle/cfg5_fixture.py)
             worst = -1e30
-            for _ in range(4):
+            for rnd in range(6):
                 sweep(True, mu)
                 worst = sweep(False, mu)[1]
+                log(f"  config-5 id check: planting round {rnd}, smallest margin {worst:.1f}")
                 if worst >= margin - 5.0:
                     break
         os.environ["VACNIC_DECODE_PER_OP"] = "1"
@@ -294,6 +307,7 @@ def config5_id_check(model, cfg, margin=40.0):
         out = {"ids_match_per_op": bool(ids_step.shape == ids_per_op.shape and torch.equal(ids_step, ids_per_op)),
                "ids_match_planted": bool(ids_step.shape == want.shape and torch.equal(ids_step, want)),
                "planted_margin_min": round(worst, 1), "default_path": path, "tokens": int(ids_step.shape[1]),
+               "first_tokens": {"planted": chain[:8], "step_kernel": ids_step[0, :8].tolist(), "per_op": ids_per_op[0, :8].tolist()},
                "note": f"full-size model conditioned like tests/golden's config-5 fixture (temporary weight scales + one planted 48-token "
                        f"caption, margin {margin:.0f} logit units), beam 5, max_length 50, lp 2.0, min_length 49"}
     finally:

@@ -313,6 +313,8 @@ int vacnic_prep_ids(const int64_t* ids, uint8_t* mask, int64_t* shifted, int64_t
                     int64_t pad_id, int64_t start_id, void* stream);
 /* face mask = (face_emb[:, :, -1] != 1) as uint8 (TRAIN:269; pad faces are all-ones rows, DSG:48,124). */
 int vacnic_face_mask(const float* faces, uint8_t* mask, int64_t BF, int64_t D, void* stream);
+/* out[B, na+nb] = cat(a[B,na], b[B,nb], dim 1) on bytes: fm = torch.cat((face_mask, name_mask), dim=1), MFULL:1262 */
+int vacnic_cat2_u8(const uint8_t* a, const uint8_t* b, uint8_t* out, int64_t B, int64_t na, int64_t nb, void* stream);
 /* per-row argmax over V logits (greedy decode / eval_epoch TRAIN:424): lowest index wins ties. */
 int vacnic_argmax_rows(const void* logits, int64_t* out, int64_t R, int64_t V, int64_t ldl,
                        int32_t logits_f32, void* stream);

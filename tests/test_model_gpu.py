@@ -822,6 +822,51 @@ def test_whole_step_hipgraph_replays_like_eager():
         streams.enable(False)
 
 
+@pytest.mark.parametrize("side_streams", [True, False])
+def test_planned_step_replays_like_eager(side_streams):
+    """launch plans (include/vacnic_hip.h): the full step recorded once through the C-ABI — kernels of every stream and the
+    fences between them — and replayed from C++ with one call per step must train like eager steps on the same batches:
+    the losses of three replayed steps on three different batches, and the final weights, against the eager run (dropout off
+    so the runs are comparable; the weight gradients are bitwise reproducible, so the tolerance only covers the LayerNorm
+    parameter atomics).  Also: a replay is ONE C-ABI call, and the eager step of explicit scheduling contains no kernel the
+    recorder cannot see (a missed kernel would freeze part of the step and the losses would drift apart)."""
+    from vacnic_amd import _lib, ops, streams, synthetic
+    from vacnic_amd.config import ClipVisionConfig
+    from vacnic_amd.training import FusedAdamW, PlannedTrainStep, TrainArgs, build_models, to_device, train_step
+    cfg = small_cfg(dropout=0.0, encoder_layers=2, decoder_layers=2, enc_fusion_layer=[0, 1])
+    vcfg = ClipVisionConfig(width=768, layers=1, patch_size=16, image_size=32, output_dim=64)
+    args = TrainArgs(num_training_steps=20, warmup_rate=0.1, lr_bart=1e-4)
+    batches = [to_device(synthetic.make_batch(cfg, 3, S=32, T=12, F=3, seed=40 + i, image_size=32), "cuda") for i in range(3)]
+    streams.enable(side_streams)
+    try:
+        runs, weights = [], []
+        for planned in (False, True):
+            ops.Rng.manual_seed(3); ops.Rng.device_counter().zero_()
+            model, guide, _ = build_models(cfg, vcfg, init="synthetic", seed=0)
+            opt = FusedAdamW(model.arena, lr=args.lr_bart, weight_decay=args.weight_decay, num_warmup_steps=2, num_training_steps=20)
+            if planned:
+                step = PlannedTrainStep(model, guide, opt, args, batches[0], warmup=2)      # 2 eager steps + the recorded (executed) one
+                assert step.commands > 100
+                losses = []
+                for b in batches[1:] + batches[:1]:
+                    c0 = _lib.CALLS
+                    losses.append(step(b).tolist())
+                    assert _lib.CALLS - c0 == 1, "a replayed step is one C-ABI call"
+                step.close()
+            else:
+                for _ in range(3):
+                    train_step(model, guide, opt, batches[0], args)
+                losses = [train_step(model, guide, opt, b, args).tolist() for b in batches[1:] + batches[:1]]
+            torch.cuda.synchronize()
+            runs.append(np.array(losses))
+            weights.append(model.arena.flat32.clone())
+        assert np.isfinite(runs[1]).all()
+        np.testing.assert_allclose(runs[1], runs[0], rtol=2e-3, atol=1e-4)
+        assert rel(weights[1], weights[0]) < 1e-4, rel(weights[1], weights[0])
+    finally:
+        streams.enable(False)
+
+
 @pytest.mark.parametrize("variant", ["slots", "barrier"])
 @pytest.mark.parametrize("case", ["bart_base_shape", "bart_large_shape"])
 def test_decoder_step_kernel_matches_per_op_path(case, variant, monkeypatch):

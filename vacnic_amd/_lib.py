@@ -160,6 +160,7 @@ _PLAIN_FNS = {
     "vacnic_vit_assemble": [vp, vp, vp, vp, i64, i64, i64, vp],
     "vacnic_prep_ids": [vp, vp, vp, i64, i64, i64, i64, vp],
     "vacnic_face_mask": [vp, vp, i64, i64, vp],
+    "vacnic_cat2_u8": [vp, vp, vp, i64, i64, i64, vp],
     "vacnic_argmax_rows": [vp, vp, i64, i64, i64, i32, vp],
     "vacnic_bias_grad": [vp, vp, i64, i64, i64, vp],
     "vacnic_add_bf16": [vp, vp, vp, i64, vp],

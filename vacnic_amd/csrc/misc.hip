@@ -240,6 +240,27 @@ extern "C" int vacnic_prep_ids(const int64_t* ids, uint8_t* mask, int64_t* shift
   VLAUNCH_CHECK();
   return VACNIC_OK;
 }
+namespace {
+__global__ void cat2_u8_kernel(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, uint8_t* __restrict__ out, int64_t B, int64_t na,
+                               int64_t nb) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n = na + nb;
+  if (i >= B * n) return;
+  const int64_t r = i / n, c = i - r * n;
+  out[i] = c < na ? a[r * na + c] : b[r * nb + (c - na)];
+}
+}  // namespace
+
+// out[B, na + nb] = cat(a[B, na], b[B, nb], dim 1) on bytes: the [faces ; names] key mask of MFULL:1262 (torch.cat of two masks)
+extern "C" int vacnic_cat2_u8(const uint8_t* a, const uint8_t* b, uint8_t* out, int64_t B, int64_t na, int64_t nb, void* stream) {
+  VPLAN_REC(vacnic_cat2_u8, a, b, out, B, na, nb, stream);
+  VCHECK(a && b && out && B > 0 && na >= 0 && nb >= 0 && na + nb > 0, VACNIC_BAD_SHAPE, "cat2_u8: bad operand");
+  const int64_t tot = B * (na + nb);
+  hipLaunchKernelGGL(cat2_u8_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, B, na, nb);
+  VLAUNCH_CHECK();
+  return VACNIC_OK;
+}
+
 extern "C" int vacnic_face_mask(const float* faces, uint8_t* mask, int64_t BF, int64_t D, void* stream) {
   VPLAN_REC(vacnic_face_mask, faces, mask, BF, D, stream);
   VCHECK(faces && mask, VACNIC_BAD_SHAPE, "face_mask: null operand");

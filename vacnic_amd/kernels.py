@@ -52,12 +52,26 @@ class launch_on:
         return False
 
 
+_KEEP = None            # streams.py's keep-list: tensors handed to a kernel on a side stream stay referenced until the join
+
+
 def _p(t):
     if t is None:
         return None
     if not t.is_cuda:
         raise RuntimeError("vacnic_amd kernels need CUDA/HIP tensors (there is no CPU fallback)")
+    if _OVERRIDE is not None and _KEEP is not None:
+        # launched on a side stream while torch's allocator believes everything lives on the current stream: the block must not be
+        # handed out again before the compute stream has joined that side stream (streams.join_all drops the references)
+        _KEEP.append(t)
     return t.data_ptr()
+
+
+def fence(src_raw, dst_raw):
+    """stream `dst` waits for everything enqueued on stream `src` so far (raw hipStream_t handles) — the recordable form of
+    event.record(src); dst.wait_event(event) (vacnic_stream_fence): cross-stream edges are part of a launch plan."""
+    if src_raw != dst_raw:
+        call("vacnic_stream_fence", src_raw, dst_raw)
 
 
 def _row_stride(t):
@@ -449,6 +463,14 @@ def face_mask(face_emb):
     mask = torch.empty((B, F), device=face_emb.device, dtype=torch.uint8)
     call("vacnic_face_mask", _p(face_emb), _p(mask), B * F, D, _stream())
     return mask
+
+
+def cat_masks(a, b):
+    """torch.cat((a, b), dim=1) for two uint8 [B, n] masks (MFULL:1262)."""
+    assert a.dtype == torch.uint8 and b.dtype == torch.uint8 and a.is_contiguous() and b.is_contiguous() and a.shape[0] == b.shape[0]
+    out = torch.empty((a.shape[0], a.shape[1] + b.shape[1]), device=a.device, dtype=torch.uint8)
+    call("vacnic_cat2_u8", _p(a), _p(b), _p(out), a.shape[0], a.shape[1], b.shape[1], _stream())
+    return out
 
 
 def argmax_rows(logits, V):

@@ -194,17 +194,36 @@ class BartEncoderLayer(nn.Module):
         return ops.add_ln(x, res, ln.weight, ln.bias, self.dropout if drop else 0.0, self.training)
 
     def forward(self, hidden_states, key_mask, hidden_states_img=None, hidden_states_face=None, hidden_states_ner=None,
-                face_name_key_mask=None, add_ner_ffn=True, fused=True):
+                face_name_key_mask=None, add_ner_ffn=True, fused=True, on_branch=False):
+        """on_branch (explicit scheduling only): the image / face / name inputs were produced on the branch stream by an earlier
+        layer; the caller (BartEncoder) hops the last layer's outputs back to the compute stream."""
         h = hidden_states
         if fused:
             # The image / face / name branches (MFULL:647-691) are a dozen small kernels over 20-80 tokens per sample and are
             # independent of the text self-attention block of this layer; with side streams on (training only) they run on
             # the branch stream beside it and join before the cross-attention that consumes their output.
             br = streams.branch_stream() if (torch.is_grad_enabled() and hidden_states.is_cuda) else None
-            cur = torch.cuda.current_stream() if br is not None else None
-            if br is not None:
+            expl = br is not None and streams.explicit()
+            if expl:
+                # explicit scheduling: the branch ops are launched on the branch stream through kernels.launch_on, and the tensors
+                # that cross between the two streams go through ops.stream_hop (fence forward, mirrored fence in backward)
+                main_raw, br_raw = K._stream(), streams.raw("branch")
+                if not on_branch:
+                    ins = [t for t in (hidden_states_img, hidden_states_face, hidden_states_ner) if t is not None]
+                    outs = list(ops.stream_hop(main_raw, br_raw, *ins))
+                    hidden_states_img = outs.pop(0)
+                    if hidden_states_face is not None:
+                        hidden_states_face = outs.pop(0)
+                    if hidden_states_ner is not None:
+                        hidden_states_ner = outs.pop(0)
+                branch_ctx = K.launch_on(br_raw)
+            elif br is not None:
+                cur = torch.cuda.current_stream()
                 br.wait_stream(cur)
-            with (torch.cuda.stream(br) if br is not None else contextlib.nullcontext()):
+                branch_ctx = torch.cuda.stream(br)
+            else:
+                branch_ctx = contextlib.nullcontext()
+            with branch_ctx:
                 # img FFN (MFULL:647-653)
                 a, r = ops.mlp2_skip(hidden_states_img, self.fc1.weight, self.s_up, self.s_down)
                 hidden_states_img = self._ln(a, r, self.img_layer_norm)
@@ -242,7 +261,9 @@ class BartEncoderLayer(nn.Module):
                 kv = self.cross_attn_img_ner.project_kv(kv)        # k|v projection of the [img ; prefix] tokens: also off the text chain
             a, r = self.self_attn(h, key_mask=key_mask, skip=True)
             h = self._ln(a, r, self.self_attn_layer_norm)                                          # :697-707
-            if br is not None:
+            if expl:
+                (kv,) = ops.stream_hop(br_raw, main_raw, kv)
+            elif br is not None:
                 cur.wait_stream(br)
             a, r = self.cross_attn_img_ner(h, kv=kv, key_mask=None, skip=True)
             h = self._ln(a, r, self.img_ner_attn_layer_norm)                                       # :711-723
@@ -342,7 +363,7 @@ class BartEncoder(nn.Module):
             ln = self.layernorm_embedding_ner
             ner = ops.embed_ln(name_ids, self.embed_tokens_ner.weight, self.embed_positions_ner.weight, ln.weight, ln.bias,
                                self.embed_scale, self.dropout, self.training, self.padding_idx)           # :1254-1260
-            fn_mask = torch.cat((face_mask.to(torch.uint8), name_mask.to(torch.uint8)), dim=1).contiguous()   # :1262 (mask bytes only)
+            fn_mask = K.cat_masks(face_mask.to(torch.uint8).contiguous(), name_mask.to(torch.uint8).contiguous())   # :1262 (mask bytes only)
             face = ops.linear(ops.to_bf16(face_features), self._linear_1.weight, self.s_l1)              # :1269
         img = self.prompt_mlp(ops.to_bf16(image_features))                                               # :1274
         if self.prompt_mlp_type == "clipcap":
@@ -350,9 +371,21 @@ class BartEncoder(nn.Module):
         if self.embed_dim == 1024:
             img = ops.linear(img, self.visual_map.weight, self.s_vmap)                                   # :1277-1278
         # img_ner_mask_cross is all ones (:1280-1296) -> no key mask on the visual/name cross-attention
+        # explicit scheduling: from the first fusion layer on the image / face / name streams live on the branch stream
+        expl = streams.explicit() and streams.branch_stream() is not None and torch.is_grad_enabled() and h.is_cuda
+        on_branch = False
         for idx, layer in enumerate(self.layers):
+            fused = idx in self.fusion_layer
             h, face, ner, img = layer(h, key_mask, hidden_states_img=img, hidden_states_face=face, hidden_states_ner=ner,
-                                      face_name_key_mask=fn_mask, add_ner_ffn=add_ner_ffn, fused=idx in self.fusion_layer)
+                                      face_name_key_mask=fn_mask, add_ner_ffn=add_ner_ffn, fused=fused, on_branch=on_branch)
+            on_branch = on_branch or (fused and expl)
+        if on_branch:                               # back to the compute stream (SECLA reads the face stream; TRAIN:326-330)
+            outs = list(ops.stream_hop(streams.raw("branch"), K._stream(), *[t for t in (img, face, ner) if t is not None]))
+            img = outs.pop(0)
+            if face is not None:
+                face = outs.pop(0)
+            if ner is not None:
+                ner = outs.pop(0)
         return {"last_hidden_state": h, "hidden_states_img": img, "hidden_states_ner": ner, "hidden_states_face": face}
 
 

@@ -61,6 +61,53 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _bw(fn):
+    """decorator of Function.backward: launch on the HIP stream the op's forward was launched on (ctx.raw, set by _tag).  With
+    explicit scheduling torch sees one stream, so the autograd engine no longer puts a node's backward on its forward's stream
+    (nor synchronises around it: the fences are ours, StreamHopFn)."""
+    def backward(ctx, *grads):
+        raw = getattr(ctx, "raw", None)
+        if raw is None or raw == K._OVERRIDE:
+            return fn(ctx, *grads)
+        with K.launch_on(raw):
+            return fn(ctx, *grads)
+    return staticmethod(backward)
+
+
+def _tag(ctx):
+    ctx.raw = K._OVERRIDE
+
+
+class StreamHopFn(Function):
+    """identity on tensors that cross from HIP stream `src` (where they were produced) to stream `dst` (where they are consumed):
+    forward = fence(src -> dst); backward = fence(dst -> src), issued by the autograd engine exactly when all the gradients of the
+    crossing tensors have been enqueued on dst.  The explicit counterpart of what the engine does implicitly for ops run under
+    torch.cuda.stream()."""
+
+    @staticmethod
+    def forward(ctx, src, dst, *xs):
+        ctx.hop = (src, dst)
+        ctx.set_materialize_grads(False)           # an output nobody differentiates keeps a None gradient (no zero-fill kernel)
+        K.fence(src, dst)
+        return tuple(x.view_as(x) for x in xs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        src, dst = ctx.hop
+        K.fence(dst, src)
+        return (None, None) + gs
+
+
+def stream_hop(src, dst, *xs):
+    """xs, usable on stream dst (see StreamHopFn).  Tensors that need no gradient are fenced without a graph node."""
+    if src == dst:
+        return xs
+    if torch.is_grad_enabled() and any(x.requires_grad for x in xs):
+        return StreamHopFn.apply(src, dst, *xs)
+    K.fence(src, dst)
+    return xs
+
+
 # ---- grouped weight gradients -------------------------------------------------------------------------------------------
 # A weight gradient with a long reduction (M = B*S rows) and a small output (d x d .. 4d x d) cannot fill 256 CUs without
 # split-K, and split-K sums through fp32 atomics (32 MB of them for one 1024 x 1024 gradient: ~25 of its 60 us).  Weight
@@ -112,10 +159,12 @@ class _WgradQueue:
             for _, _, sp in jobs:
                 ddp.done(sp.wgrad, sp.bgrad)
             return
-        # (the side stream already waits for every queued job's producer: add() is called behind side.wait_stream(producer))
-        if ddp.TRACKER is None:
+        # (the side stream already waits for every queued job's producer: add() is called behind a producer -> side fence)
+        if ddp.TRACKER is None or streams.explicit():
             with K.launch_on(streams.wgrad_raw()):
                 K.wgrad_group(packed)
+            for _, _, sp in jobs:
+                ddp.done(sp.wgrad, sp.bgrad)
         else:
             with torch.cuda.stream(side):
                 K.wgrad_group(packed)
@@ -156,13 +205,17 @@ def _wgrad(dy2d, x2d, spec, M):
         _wgrad_impl(dy2d, x2d, spec, M)
         ddp.done(spec.wgrad, spec.bgrad)
         return
-    side.wait_stream(torch.cuda.current_stream())          # dy / x were produced on the compute stream
+    if streams.explicit():
+        K.fence(K._stream(), streams.wgrad_raw())          # dy / x were produced on the stream this backward node launches on
+    else:
+        side.wait_stream(torch.cuda.current_stream())      # dy / x were produced on the compute stream
     if group:
         _WGQ.add(dy2d, x2d, spec, M)
         return
-    if ddp.TRACKER is None:
+    if ddp.TRACKER is None or streams.explicit():
         with K.launch_on(streams.wgrad_raw()):
             _wgrad_impl(dy2d, x2d, spec, M)
+        ddp.done(spec.wgrad, spec.bgrad)
     else:
         with torch.cuda.stream(side):                      # the bucket launcher reads torch's current stream
             _wgrad_impl(dy2d, x2d, spec, M)
@@ -196,6 +249,7 @@ class LinearFn(Function):
 
     @staticmethod
     def forward(ctx, x, anchor, spec, residual, ge, skip):
+        _tag(ctx)
         Kd = spec.K
         x2 = _c(x).view(-1, Kd)
         M = x2.shape[0]
@@ -210,7 +264,7 @@ class LinearFn(Function):
             return out, x.view_as(x)
         return out
 
-    @staticmethod
+    @_bw
     def backward(ctx, dy, dskip=None):
         (x2,) = ctx.saved_tensors
         spec, M = ctx.spec, ctx.M
@@ -244,6 +298,7 @@ class Mlp2Fn(Function):
 
     @staticmethod
     def forward(ctx, x, anchor, s1, s2, act, ge, skip=False):
+        _tag(ctx)
         x2 = _c(x).view(-1, s1.K)
         M = x2.shape[0]
         need = ge and any(ctx.needs_input_grad)      # grad mode is always off inside Function.forward: `ge` comes from the caller
@@ -259,7 +314,7 @@ class Mlp2Fn(Function):
             return out, x.view_as(x)             # residual branch: its gradient joins in the last dgrad GEMM's epilogue
         return out
 
-    @staticmethod
+    @_bw
     def backward(ctx, dy, dskip=None):
         x2, u, h = ctx.saved_tensors
         s1, s2, act, M = ctx.s1, ctx.s2, ctx.act, ctx.M
@@ -299,6 +354,7 @@ class MlpChainFn(Function):
 
     @staticmethod
     def forward(ctx, x, anchor, specs, act, ge):
+        _tag(ctx)
         s0 = specs[0]
         x2 = _c(x).view(-1, s0.K)
         M = x2.shape[0]
@@ -326,7 +382,7 @@ class MlpChainFn(Function):
             ddp.expect(need, sp.wgrad, sp.bgrad)
         return h
 
-    @staticmethod
+    @_bw
     def backward(ctx, dy):
         saved = ctx.saved_tensors
         specs, act, M = ctx.specs, ctx.act, ctx.M
@@ -362,6 +418,7 @@ class SelfAttnFn(Function):
 
     @staticmethod
     def forward(ctx, kvq, key_mask, causal, H, ge):
+        _tag(ctx)
         B, T, d3 = kvq.shape
         d = d3 // 3
         out, lse = K.attn_fwd(kvq[..., 2 * d:], kvq[..., :d], kvq[..., d:2 * d], B, H, T, T, key_mask=key_mask,
@@ -371,7 +428,7 @@ class SelfAttnFn(Function):
         ctx.save_for_backward(kvq, out, lse)
         return out
 
-    @staticmethod
+    @_bw
     def backward(ctx, dout):
         kvq, out, lse = ctx.saved_tensors
         B, H, T, d, causal = ctx.cfg
@@ -387,6 +444,7 @@ class CrossAttnFn(Function):
 
     @staticmethod
     def forward(ctx, q, kv, key_mask, H, ge, bank=None, slot=0):
+        _tag(ctx)
         B, Tq, d = q.shape
         Tk = kv.shape[1]
         out, lse = K.attn_fwd(q, kv[..., :d], kv[..., d:], B, H, Tq, Tk, key_mask=key_mask, causal=False, scale=0.125,
@@ -397,7 +455,7 @@ class CrossAttnFn(Function):
         ctx.save_for_backward(q, kv, out, lse)
         return out
 
-    @staticmethod
+    @_bw
     def backward(ctx, dout):
         q, kv, out, lse = ctx.saved_tensors
         B, H, Tq, Tk, d = ctx.cfg
@@ -435,10 +493,11 @@ class SplitKvFn(Function):
 
     @staticmethod
     def forward(ctx, kv_all, bank):
+        _tag(ctx)
         ctx.bank = bank
         return tuple(bank.slot(kv_all, l) for l in range(bank.L))
 
-    @staticmethod
+    @_bw
     def backward(ctx, *grads):
         bank = ctx.bank
         for l, g in enumerate(grads):
@@ -474,6 +533,7 @@ class AddLnFn(Function):
 
     @staticmethod
     def forward(ctx, x, residual, gamma, beta, p_drop, seed, ge):
+        _tag(ctx)
         x = _c(x)
         res = _c(residual) if residual is not None else None
         need = ge and any(ctx.needs_input_grad)
@@ -486,7 +546,7 @@ class AddLnFn(Function):
         ddp.expect(need, gamma.grad, beta.grad)
         return out
 
-    @staticmethod
+    @_bw
     def backward(ctx, dout):
         x, res, mean, rstd = ctx.saved_tensors
         gamma, beta = ctx.gb
@@ -507,6 +567,7 @@ class EmbedLnFn(Function):
 
     @staticmethod
     def forward(ctx, ids, tok, pos, gamma, beta, scale, p_drop, seed, padding_idx, ge):
+        _tag(ctx)
         out, mean, rstd = K.embed_ln_fwd(ids, tok.w16, pos.w16, gamma, beta, embed_scale=scale, p_drop=p_drop, seed=seed,
                                          seed_dev=Rng.device_counter() if p_drop > 0 else None)
         ctx.args = (tok, pos, gamma, beta, scale, p_drop, seed, padding_idx)
@@ -514,7 +575,7 @@ class EmbedLnFn(Function):
         ddp.expect(ge and any(ctx.needs_input_grad), tok.grad, pos.grad, gamma.grad, beta.grad)
         return out
 
-    @staticmethod
+    @_bw
     def backward(ctx, dout):
         ids, mean, rstd = ctx.saved_tensors
         tok, pos, gamma, beta, scale, p, seed, pad = ctx.args
@@ -535,9 +596,10 @@ class ForkFn(Function):
 
     @staticmethod
     def forward(ctx, x):
+        _tag(ctx)
         return x.view_as(x), x.view_as(x)
 
-    @staticmethod
+    @_bw
     def backward(ctx, g1, g2):
         if g1 is None:
             return g2
@@ -557,10 +619,11 @@ class CatTokensFn(Function):
 
     @staticmethod
     def forward(ctx, *parts):
+        _tag(ctx)
         ctx.lens = [p.shape[1] for p in parts]
         return K.cat_tokens([_c(p) for p in parts])
 
-    @staticmethod
+    @_bw
     def backward(ctx, g):
         g = _c(g)
         B, _, D = g.shape
@@ -585,9 +648,10 @@ class CastInFn(Function):
 
     @staticmethod
     def forward(ctx, x):
+        _tag(ctx)
         return K.cast_f32_bf16(_c(x))
 
-    @staticmethod
+    @_bw
     def backward(ctx, g):
         return None
 
@@ -609,6 +673,7 @@ class LmHeadCeFn(Function):
 
     @staticmethod
     def forward(ctx, h, anchor, emb16_pad, egrad, targets, V, ignore_index, ge):
+        _tag(ctx)
         d = h.shape[-1]
         h2 = _c(h).view(-1, d)
         tgt = _c(targets).view(-1)
@@ -620,7 +685,7 @@ class LmHeadCeFn(Function):
         ddp.expect(ge and any(ctx.needs_input_grad), egrad)
         return out4[1], acc
 
-    @staticmethod
+    @_bw
     def backward(ctx, g, _gacc):
         h2, tgt, row_lse, acc = ctx.saved_tensors
         emb16_pad, egrad, V, ignore_index, R, d, hshape = ctx.misc
@@ -654,12 +719,13 @@ class ColamFn(Function):
 
     @staticmethod
     def forward(ctx, hs, hg, mask_u8, margin, weight):
+        _tag(ctx)
         loss, cos, ps, pg = K.colam_fwd(_c(hs), _c(hg), mask_u8, margin)
         ctx.misc = (mask_u8, tuple(hs.shape), margin, weight)
         ctx.save_for_backward(cos, ps, pg)
         return loss
 
-    @staticmethod
+    @_bw
     def backward(ctx, g):
         cos, ps, pg = ctx.saved_tensors
         mask_u8, shape, margin, weight = ctx.misc
@@ -671,16 +737,28 @@ class SeclaFn(Function):
 
     @staticmethod
     def forward(ctx, faces, names, weight):
+        _tag(ctx)
         faces = _c(faces)
         loss, sim, l1, l2 = K.secla_fwd(faces, names)
         ctx.weight = weight
         ctx.save_for_backward(faces, names, sim, l1, l2)
         return loss
 
-    @staticmethod
+    @_bw
     def backward(ctx, g):
         faces, names, sim, l1, l2 = ctx.saved_tensors
         return K.secla_bwd(faces, names, sim, l1, l2, _c(g), ctx.weight), None, None
+
+
+_ONES = {}
+
+
+def _const_one(device):
+    """fp32 scalar 1.0 on `device`, created once (no fill kernel per step)."""
+    t = _ONES.get(device)
+    if t is None:
+        t = _ONES[device] = torch.ones((), device=device, dtype=torch.float32)
+    return t
 
 
 class TotalLossFn(Function):
@@ -689,13 +767,14 @@ class TotalLossFn(Function):
 
     @staticmethod
     def forward(ctx, txt, secla, colam, w_secla, w_colam):
-        one = torch.ones((), device=txt.device, dtype=torch.float32)
+        _tag(ctx)
+        one = _const_one(txt.device)
         out4 = K.combine_losses(txt.data_ptr(), one.data_ptr(), secla, colam, w_secla, w_colam, txt.device)
         ctx.has = (secla is not None, colam is not None)
         ctx.mark_non_differentiable(out4)
         return out4[0], out4
 
-    @staticmethod
+    @_bw
     def backward(ctx, g, _g4):
         return g, (g if ctx.has[0] else None), (g if ctx.has[1] else None), None, None
 

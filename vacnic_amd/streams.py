@@ -12,9 +12,15 @@ Ordering is by events.  Tensors consumed on the weight-gradient stream are kept 
 stream has joined that stream (`join_all`), NOT by Tensor.record_stream(): with recorded blocks outstanding the caching
 allocator polls their events on every allocation, which cost ~14 us per torch.empty (16 ms of host time per step).
 """
+import os
+
 import torch
 
-_state = {"enabled": False, "wgrad": None, "aux": None, "vit": None, "branch": None, "wgrad_raw": None, "keep": []}
+from . import kernels as _K
+
+_state = {"enabled": False, "wgrad": None, "aux": None, "vit": None, "branch": None, "wgrad_raw": None, "keep": [],
+          "explicit": os.environ.get("VACNIC_EXPLICIT_STREAMS", "1") != "0"}
+_K._KEEP = _state["keep"]
 
 
 def enable(flag=True):
@@ -25,6 +31,20 @@ def enable(flag=True):
         _state["aux"] = torch.cuda.Stream()
         _state["vit"] = torch.cuda.Stream()
         _state["branch"] = torch.cuda.Stream()
+
+
+def explicit():
+    """Explicit scheduling (default): side-stream work is launched through kernels.launch_on(raw stream) and every cross-stream
+    edge is a kernels.fence() — torch (allocator, autograd engine) sees ONE stream, so no synchronisation is hidden inside
+    torch and the step's launch sequence, fences included, can be recorded into a launch plan (training.PlannedTrainStep).
+    VACNIC_EXPLICIT_STREAMS=0: torch.cuda.stream() contexts and the autograd engine's own stream syncs (the round-1/2 schedule)."""
+    return _state["explicit"]
+
+
+def raw(name):
+    """raw hipStream_t of side stream 'wgrad' | 'aux' | 'vit' | 'branch' (None when side streams are off)."""
+    s = _state[name] if _state["enabled"] else None
+    return s.cuda_stream if s is not None else None
 
 
 def enabled():
@@ -44,6 +64,10 @@ def keep(*tensors):
     compute stream joins the weight-gradient stream early."""
     k = _state["keep"]
     k.extend(tensors)
+    if _state["explicit"]:
+        if len(k) > (1 << 18):                    # (only a caller that never joins gets here)
+            join_all()
+        return
     if len(k) > 8192:
         # early release: every stream a kept tensor may have been allocated on (the compute stream and the branch stream, whose
         # blocks go back to THEIR pools) must be ordered behind the weight-gradient stream's reads before the references drop
@@ -74,6 +98,12 @@ def vit_stream():
 
 def join_all():
     """make the current stream wait for everything issued on the side streams (before AdamW / the all-reduce tail)."""
+    if _state["enabled"] and _state["explicit"]:
+        cur = _K._stream()
+        for name in ("wgrad", "aux", "vit", "branch"):
+            _K.fence(_state[name].cuda_stream, cur)
+        _state["keep"].clear()
+        return
     if _state["enabled"]:
         cur = torch.cuda.current_stream()
         cur.wait_stream(_state["wgrad"])

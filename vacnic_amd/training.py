@@ -163,6 +163,27 @@ def forward_losses(model, guide, batch, args: TrainArgs, ready=None, towers=None
         img_cls, gh = towers.img_cls, towers.gh
         for tns in (src_mask, tgt_mask, tgt_in):
             tns.record_stream(main)
+    elif streams.explicit():
+        # explicit scheduling (see streams.explicit): the same schedule as the branch below — id preprocessing + frozen guide
+        # forward on the aux stream, frozen ViT on its own stream — with kernels.launch_on / kernels.fence instead of
+        # torch.cuda.stream contexts and Tensor.record_stream, so that the whole step can be recorded into a launch plan
+        main_raw, aux_raw, vis_raw = K._stream(), streams.raw("aux"), streams.raw("vit")
+        if ready is None:
+            K.fence(main_raw, aux_raw)
+            K.fence(main_raw, vis_raw)
+        else:                                   # (a torch event of the loader: not part of a plan — plans refresh their inputs in place)
+            aux.wait_event(ready)
+            vis.wait_event(ready)
+        with K.launch_on(aux_raw):
+            src_mask, _ = K.prep_ids(src, cfg.pad_token_id)
+            tgt_mask, tgt_in = K.prep_ids(tgt, cfg.pad_token_id, start_id=cfg.eos_token_id)
+        K.fence(aux_raw, main_raw)              # the student needs the masks now, the guide's output only at the CoLaM loss
+        with K.launch_on(vis_raw):              # the student's encoder input needs the image feature: ViT goes first
+            img_cls = extract_clip_img_feat(net.clip_model, batch["img_tensor"])[feat]
+        if guide is not None:
+            with K.launch_on(aux_raw):
+                gh = guide(input_ids=src, attention_mask=src_mask, decoder_input_ids=tgt_in)["decoder_hidden_states"][-1]   # TRAIN:293-294
+        K.fence(vis_raw, main_raw)
     else:
         # id preprocessing + frozen guide forward on the aux stream, frozen ViT on its own stream: they depend only on
         # the batch, so they fill the bubbles of the main chain (and of the previous step's AdamW)
@@ -197,7 +218,9 @@ def forward_losses(model, guide, batch, args: TrainArgs, ready=None, towers=None
     txt = out["loss"]
     colam = secla = None
     if guide is not None:
-        if aux is not None:
+        if aux is not None and towers is None and streams.explicit():
+            K.fence(streams.raw("aux"), K._stream())
+        elif aux is not None:
             main.wait_stream(aux)
             if towers is None:
                 gh.record_stream(main)
@@ -328,6 +351,60 @@ class GraphedTrainStep:
             v.copy_(batch[k], non_blocking=True)
         self.graph.replay()
         return self.out4
+
+
+class PlannedTrainStep:
+    """The whole training step — frozen towers, forward, losses, backward, AdamW; every stream — as a LAUNCH PLAN: the step's
+    C-ABI call sequence (kernel launches AND the fences between streams) is recorded once by the library while one step runs
+    eagerly, and every later step is ONE call, vacnic_plan_replay, which re-issues the same launches on the same streams in the
+    same order from C++ (include/vacnic_hip.h "launch plans").  The GPU-side schedule is the eager multi-stream one (a hipGraph
+    of the step, GraphedTrainStep, runs its branches less concurrently and is slower); the ~1250 Python -> ctypes -> autograd
+    round trips per step are gone from the launch path.
+
+    What makes a step replayable: explicit scheduling (streams.explicit(): no stream synchronisation hidden inside torch), no
+    host<->device sync and no ATen kernel inside the step, per-step scalars in device memory (LR, step and dropout counters:
+    vacnic_lr_step), and every buffer at its recorded address — the recording runs inside a private allocator pool that is
+    kept, inputs are copied into static tensors before each replay.  world_size 1 (the DDP reducer launches its collectives
+    from Python between backward nodes; it keeps the eager path)."""
+
+    def __init__(self, model, guide, optimizer, args: TrainArgs, example_batch, warmup=2):
+        from . import _lib
+        if isinstance(model, DistributedDataParallel) and model.world > 1:
+            raise RuntimeError("PlannedTrainStep: world_size 1 only (the reducer's bucket launches are host-side)")
+        if streams.enabled() and not streams.explicit():
+            raise RuntimeError("PlannedTrainStep needs explicit scheduling (VACNIC_EXPLICIT_STREAMS=0 is set)")
+        self.static = {k: v.clone() for k, v in example_batch.items()}
+        for _ in range(warmup):                              # eager: lazy buffers, kernel loading, allocator warm-up
+            train_step(model, guide, optimizer, self.static, args)
+        torch.cuda.synchronize()
+        self.stream = K._stream()
+        self.pool = torch.cuda.MemPool()
+        self.handle = int(_lib.lib.vacnic_plan_begin())
+        if self.handle < 0:
+            _lib.check(1)
+        try:
+            with torch.cuda.use_mem_pool(self.pool):
+                self.out4 = train_step(model, guide, optimizer, self.static, args)
+        finally:
+            _lib.check(_lib.lib.vacnic_plan_end(self.handle))
+        torch.cuda.synchronize()
+        self.commands = int(_lib.lib.vacnic_plan_size(self.handle))
+
+    def __call__(self, batch):
+        from . import _lib
+        if K._stream() != self.stream:
+            raise RuntimeError("PlannedTrainStep: replay on the stream the plan was recorded on")
+        for k, v in self.static.items():
+            if batch[k] is not v:
+                v.copy_(batch[k], non_blocking=True)
+        _lib.call("vacnic_plan_replay", self.handle, 0, self.commands)
+        return self.out4
+
+    def close(self):
+        from . import _lib
+        if self.handle is not None:
+            _lib.check(_lib.lib.vacnic_plan_destroy(self.handle))
+            self.handle = None
 
 
 class FrozenTowerGraphs:
