@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="replay the step as one captured hipGraph (world 1 only). Measured slower than "
                     "eager multi-stream launches while the step is GPU-bound (91.0 vs 86.2 ms: hipGraph runs the side-stream branches "
                     "less concurrently), so eager is the default")
+    ap.add_argument("--plan", action="store_true", help="replay the step as a recorded launch plan (vacnic_plan_replay: one C-ABI call per step, the "
+                    "eager multi-stream schedule re-issued from C++; world 1)")
     ap.add_argument("--mock-step", action="store_true", help=argparse.SUPPRESS)    # tests/test_bench_launch.py: launcher plumbing without a GPU
     return ap.parse_args()
 
@@ -466,7 +468,7 @@ def main():
     from vacnic_amd import synthetic
     from vacnic_amd.config import bart_large_vit_l14
     from vacnic_amd.ddp import DistributedDataParallel
-    from vacnic_amd.training import FrozenTowerGraphs, FusedAdamW, GraphedTrainStep, TrainArgs, build_models, to_device, train_step
+    from vacnic_amd.training import FrozenTowerGraphs, FusedAdamW, GraphedTrainStep, PlannedTrainStep, TrainArgs, build_models, to_device, train_step
 
     from vacnic_amd import streams
     streams.enable(not a.no_streams)
@@ -486,7 +488,7 @@ def main():
     ready.record()                      # the synthetic batches are resident and complete: frozen towers may start on this
 
     towers = None
-    if not a.no_streams and not a.no_tower_graphs and not a.graph:
+    if not a.no_streams and not a.no_tower_graphs and not a.graph and not a.plan:
         try:
             towers = FrozenTowerGraphs(model, guide, batches[0])
             log("frozen towers (guide BART, CLIP ViT) captured as hipGraphs")
@@ -514,7 +516,18 @@ def main():
             log(f"graph capture failed ({e!r}); falling back to eager launches")
             graphed = None
             torch.cuda.synchronize()
-    if graphed is None:
+    planned = None
+    if world == 1 and a.plan and graphed is None:
+        try:
+            planned = PlannedTrainStep(net, guide, opt, args, batches[0], warmup=max(1, a.warmup - 1))
+            planned(batches[1 % nb])
+            torch.cuda.synchronize()
+            log(f"launch plan recorded ({planned.commands} commands) and replayed once")
+        except Exception as e:                      # never lose the measurement to a recording problem
+            log(f"plan recording failed ({e!r}); falling back to eager launches")
+            planned = None
+            torch.cuda.synchronize()
+    if graphed is None and planned is None:
         for i in range(a.warmup):
             train_step(net, guide, opt, batches[i % nb], args, ready, towers)
             torch.cuda.synchronize()
@@ -540,6 +553,8 @@ def main():
             streams.enable(not a.no_streams)
         elif graphed is not None:
             out4 = graphed(bt)
+        elif planned is not None:
+            out4 = planned(bt)
         else:
             out4 = train_step(net, guide, opt, bt, args, ready, towers)
     timer.remove()
@@ -597,6 +612,7 @@ def main():
                                       f"224x224 image, {S}-token article, {T}-token caption, per-GPU batch {B}, dropout 0.1, fp32 master + bf16 compute",
                           "global_batch": B * world, "seq_len": S, "caption_len": T, "parallelism": f"dp{world}"},
                "launch_mode": ("hipGraph replay (K-1 steps) + 1 eager instrumented step" if graphed is not None else
+                               f"launch plan replay ({planned.commands} recorded commands, 1 C-ABI call per step; K-1 steps) + 1 eager instrumented step" if planned is not None else
                                "eager multi-stream" + (", frozen towers as hipGraph replays" if towers is not None else "")),
                "host_enqueue_ms_per_step": round(host_dt / a.steps * 1e3, 2),
                "c_abi_calls_per_step": round(calls_per_step, 1), "host_cpu_ms_per_step": round(host_cpu * 1e3, 2),

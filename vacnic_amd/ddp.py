@@ -139,7 +139,9 @@ class DistributedDataParallel(torch.nn.Module):
             for s in (streams.wgrad_stream(), streams.branch_stream(), torch.cuda.default_stream()):
                 if s is not None:
                     self.comm_stream.wait_stream(s)
-            with torch.cuda.stream(self.comm_stream):
+            # (a bucket may complete inside a kernels.launch_on section — a branch-stream backward node: the casts below belong
+            # on the comm stream whatever stream override is in force)
+            with torch.cuda.stream(self.comm_stream), K.launch_on(self.comm_stream.cuda_stream, fence=False):
                 if s16 is None:
                     self.works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
                 else:

@@ -36,14 +36,23 @@ def _stream():
 
 class launch_on:
     """with launch_on(raw_stream): every vacnic kernel wrapper inside launches on that HIP stream (torch's notion of the
-    current stream is untouched, so allocations stay on the caller's stream — the caller owns the ordering/lifetime)."""
+    current stream is untouched, so allocations stay on the caller's stream — the caller owns the ordering/lifetime).
 
-    def __init__(self, raw):
-        self.raw = raw
+    fence=True (default): the side stream first waits for everything enqueued on torch's current stream so far.  torch's
+    allocator believes every block lives on the current stream and hands a freed block out again at once; a kernel launched on
+    the side stream into such a block must not overtake the compute-stream kernels that were still using it.  (Blocks a
+    side-stream kernel uses are held by the keep-list until the compute stream has joined that stream: kernels._p.)"""
+
+    def __init__(self, raw, fence=True):
+        self.raw, self.fence = raw, fence
 
     def __enter__(self):
         global _OVERRIDE
         self.prev = _OVERRIDE
+        if self.fence and self.raw is not None and self.raw != self.prev:
+            cur = _raw_stream(torch.cuda.current_device()) if _raw_stream is not None else torch.cuda.current_stream().cuda_stream
+            if cur != self.raw:
+                call("vacnic_stream_fence", cur, self.raw)
         _OVERRIDE = self.raw
 
     def __exit__(self, *exc):

@@ -130,8 +130,13 @@ def extract_clip_img_feat(clip_model, x):
         vis = clip_model.visual
         if vis.arena is None:
             raise RuntimeError("call clip_model.finalize(device) first")
-        patches, cls = vis.features(x)
-        return K.cast_bf16_f32(patches.contiguous()), K.cast_bf16_f32(cls.contiguous())
+        patches, cls = vis.features(x)                    # strided views of one [B, 1 + g*g, w] tensor
+        B, G2, w = patches.shape
+        pc = torch.empty((B, G2, w), device=patches.device, dtype=patches.dtype)
+        cc = torch.empty((B, 1, w), device=patches.device, dtype=patches.dtype)
+        K.copy3d(patches, pc, B, G2, w)                    # (our strided-copy kernel, not Tensor.contiguous(): no ATen kernel on the path)
+        K.copy3d(cls.unsqueeze(1), cc, B, 1, w)
+        return K.cast_bf16_f32(pc), K.cast_bf16_f32(cc.view(B, w))
 
 
 def graphed_clip_img_feat(clip_model):

@@ -76,6 +76,10 @@ def _bw(fn):
 
 def _tag(ctx):
     ctx.raw = K._OVERRIDE
+    # an output nobody differentiates (a decoder state only the caller keeps, an unused skip branch) hands None to backward
+    # instead of a zero tensor autograd would fill with an ATen kernel — 13 fills per step, and kernels the launch-plan recorder
+    # cannot see.  Every backward here treats None as "no contribution".
+    ctx.set_materialize_grads(False)
 
 
 class StreamHopFn(Function):
@@ -161,7 +165,7 @@ class _WgradQueue:
             return
         # (the side stream already waits for every queued job's producer: add() is called behind a producer -> side fence)
         if ddp.TRACKER is None or streams.explicit():
-            with K.launch_on(streams.wgrad_raw()):
+            with K.launch_on(streams.wgrad_raw(), fence=False):      # (every job fenced its producer -> wgrad stream when it was queued)
                 K.wgrad_group(packed)
             for _, _, sp in jobs:
                 ddp.done(sp.wgrad, sp.bgrad)
@@ -213,7 +217,7 @@ def _wgrad(dy2d, x2d, spec, M):
         _WGQ.add(dy2d, x2d, spec, M)
         return
     if ddp.TRACKER is None or streams.explicit():
-        with K.launch_on(streams.wgrad_raw()):
+        with K.launch_on(streams.wgrad_raw(), fence=False):
             _wgrad_impl(dy2d, x2d, spec, M)
         ddp.done(spec.wgrad, spec.bgrad)
     else:
@@ -753,7 +757,7 @@ class SeclaFn(Function):
 _ONES = {}
 
 
-def _const_one(device):
+def const_one(device):
     """fp32 scalar 1.0 on `device`, created once (no fill kernel per step)."""
     t = _ONES.get(device)
     if t is None:
@@ -768,7 +772,7 @@ class TotalLossFn(Function):
     @staticmethod
     def forward(ctx, txt, secla, colam, w_secla, w_colam):
         _tag(ctx)
-        one = _const_one(txt.device)
+        one = const_one(txt.device)
         out4 = K.combine_losses(txt.data_ptr(), one.data_ptr(), secla, colam, w_secla, w_colam, txt.device)
         ctx.has = (secla is not None, colam is not None)
         ctx.mark_non_differentiable(out4)

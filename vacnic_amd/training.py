@@ -247,7 +247,9 @@ def train_step(model, guide, optimizer, batch, args: TrainArgs, ready=None, towe
         net.train()
     total, out4, _ = forward_losses(model, guide, batch, args, ready, towers)
     with torch.autograd.set_multithreading_enabled(False):     # one device: the engine's worker-thread hop only costs host time
-        total.backward()
+        # explicit unit gradient from a persistent constant: backward()'s default ones_like(total) is a fill kernel into a fresh
+        # block per step — the one ATen kernel left inside the step (tools/aten_in_step.py), invisible to a launch plan
+        total.backward(ops.const_one(total.device))
     streams.join_all()                       # weight-gradient side stream -> compute stream
     if isinstance(model, DistributedDataParallel):
         model.reduce_gradients()
