@@ -488,7 +488,7 @@ def main():
     ready.record()                      # the synthetic batches are resident and complete: frozen towers may start on this
 
     towers = None
-    if not a.no_streams and not a.no_tower_graphs and not a.graph and not a.plan:
+    if not a.no_streams and not a.no_tower_graphs and not a.graph:
         try:
             towers = FrozenTowerGraphs(model, guide, batches[0])
             log("frozen towers (guide BART, CLIP ViT) captured as hipGraphs")
@@ -519,7 +519,7 @@ def main():
     planned = None
     if world == 1 and a.plan and graphed is None:
         try:
-            planned = PlannedTrainStep(net, guide, opt, args, batches[0], warmup=max(1, a.warmup - 1))
+            planned = PlannedTrainStep(net, guide, opt, args, batches[0], warmup=max(1, a.warmup - 1), towers=towers)
             planned(batches[1 % nb])
             torch.cuda.synchronize()
             log(f"launch plan recorded ({planned.commands} commands) and replayed once")

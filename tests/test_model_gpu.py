@@ -822,7 +822,7 @@ def test_whole_step_hipgraph_replays_like_eager():
         streams.enable(False)
 
 
-@pytest.mark.parametrize("side_streams", [True, False])
+@pytest.mark.parametrize("side_streams", [True, False, "tower_graphs"])
 def test_planned_step_replays_like_eager(side_streams):
     """launch plans (include/vacnic_hip.h): the full step recorded once through the C-ABI — kernels of every stream and the
     fences between them — and replayed from C++ with one call per step must train like eager steps on the same batches:
@@ -832,12 +832,12 @@ def test_planned_step_replays_like_eager(side_streams):
     recorder cannot see (a missed kernel would freeze part of the step and the losses would drift apart)."""
     from vacnic_amd import _lib, ops, streams, synthetic
     from vacnic_amd.config import ClipVisionConfig
-    from vacnic_amd.training import FusedAdamW, PlannedTrainStep, TrainArgs, build_models, to_device, train_step
+    from vacnic_amd.training import FrozenTowerGraphs, FusedAdamW, PlannedTrainStep, TrainArgs, build_models, to_device, train_step
     cfg = small_cfg(dropout=0.0, encoder_layers=2, decoder_layers=2, enc_fusion_layer=[0, 1])
     vcfg = ClipVisionConfig(width=768, layers=1, patch_size=16, image_size=32, output_dim=64)
     args = TrainArgs(num_training_steps=20, warmup_rate=0.1, lr_bart=1e-4)
     batches = [to_device(synthetic.make_batch(cfg, 3, S=32, T=12, F=3, seed=40 + i, image_size=32), "cuda") for i in range(3)]
-    streams.enable(side_streams)
+    streams.enable(bool(side_streams))
     try:
         runs, weights = [], []
         for planned in (False, True):
@@ -845,13 +845,15 @@ def test_planned_step_replays_like_eager(side_streams):
             model, guide, _ = build_models(cfg, vcfg, init="synthetic", seed=0)
             opt = FusedAdamW(model.arena, lr=args.lr_bart, weight_decay=args.weight_decay, num_warmup_steps=2, num_training_steps=20)
             if planned:
-                step = PlannedTrainStep(model, guide, opt, args, batches[0], warmup=2)      # 2 eager steps + the recorded (executed) one
-                assert step.commands > 100
+                # "tower_graphs": the frozen towers stay hipGraph replays launched by the host, the plan is split at two marks
+                towers = FrozenTowerGraphs(model, guide, batches[0]) if side_streams == "tower_graphs" else None
+                step = PlannedTrainStep(model, guide, opt, args, batches[0], warmup=2, towers=towers)   # 2 eager steps + the recorded (executed) one
+                assert step.commands > 100 and len(step.marks) == (2 if towers is not None else 0)
                 losses = []
                 for b in batches[1:] + batches[:1]:
                     c0 = _lib.CALLS
                     losses.append(step(b).tolist())
-                    assert _lib.CALLS - c0 == 1, "a replayed step is one C-ABI call"
+                    assert _lib.CALLS - c0 == (5 if towers is not None else 1), "a replayed step is one C-ABI call per plan segment (+ the guide's two id kernels)"
                 step.close()
             else:
                 for _ in range(3):

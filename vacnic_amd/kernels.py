@@ -467,6 +467,12 @@ def prep_ids(ids, pad_id=1, start_id=None, want_mask=True):
     return mask, shifted
 
 
+def prep_ids_into(ids, mask, shifted, pad_id=1, start_id=None):
+    """prep_ids writing into caller-owned buffers (either may be None)."""
+    B, T = ids.shape
+    call("vacnic_prep_ids", _p(ids), _p(mask), _p(shifted), B, T, pad_id, start_id if start_id is not None else 0, _stream())
+
+
 def face_mask(face_emb):
     B, F, D = face_emb.shape
     mask = torch.empty((B, F), device=face_emb.device, dtype=torch.uint8)

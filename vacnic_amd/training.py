@@ -134,6 +134,9 @@ def image_feature_index(cfg):
     return 1 if cfg.prompt_mlp_type == "clipcap" else 0
 
 
+_PLAN = None          # the PlannedTrainStep being recorded (forward_losses leaves marks in it)
+
+
 def forward_losses(model, guide, batch, args: TrainArgs, ready=None, towers=None):
     """Forward of one step; returns (total, out4={total, txt, secla, colam}, model_out).  `model` may be the DDP wrapper
     (like TRAIN:274 `model.module`).  `ready`: optional event after which the batch tensors are valid in HBM; with side
@@ -155,6 +158,12 @@ def forward_losses(model, guide, batch, args: TrainArgs, ready=None, towers=None
         src_mask, _ = K.prep_ids(src, cfg.pad_token_id)                                      # create_src_mask_bart, TRAIN:268
         tgt_mask, tgt_in = K.prep_ids(tgt, cfg.pad_token_id, start_id=cfg.eos_token_id)     # shift_tokens_right, TRAIN:267,296
         img_cls = extract_clip_img_feat(net.clip_model, batch["img_tensor"])[feat]            # TRAIN:274-276
+    elif towers is not None and _PLAN is not None:
+        # recording a launch plan around the tower graphs (PlannedTrainStep): the graphs are replayed by the host before each plan
+        # replay and joined at the plan's marks; the id preprocessing runs inside the plan, on the compute stream
+        src_mask, _ = K.prep_ids(src, cfg.pad_token_id)
+        tgt_mask, tgt_in = K.prep_ids(tgt, cfg.pad_token_id, start_id=cfg.eos_token_id)
+        img_cls, gh = towers.img_cls, towers.gh
     elif towers is not None:
         # frozen towers as two hipGraph replays on their side streams (FrozenTowerGraphs)
         src_mask, tgt_mask, tgt_in, ev_prep = towers.launch(batch, ready)
@@ -218,7 +227,9 @@ def forward_losses(model, guide, batch, args: TrainArgs, ready=None, towers=None
     txt = out["loss"]
     colam = secla = None
     if guide is not None:
-        if aux is not None and towers is None and streams.explicit():
+        if towers is not None and _PLAN is not None:
+            _PLAN.mark("join_guide")             # the host makes the compute stream wait for the guide graph here
+        elif aux is not None and towers is None and streams.explicit():
             K.fence(streams.raw("aux"), K._stream())
         elif aux is not None:
             main.wait_stream(aux)
@@ -227,7 +238,9 @@ def forward_losses(model, guide, batch, args: TrainArgs, ready=None, towers=None
         else:
             gh = guide(input_ids=src, attention_mask=src_mask, decoder_input_ids=tgt_in)["decoder_hidden_states"][-1]   # TRAIN:293-294
         colam = ops.ColamFn.apply(out["decoder_hidden_states"][-1], gh, tgt_mask, args.margin, args.alpha)        # TRAIN:296-307
-    if towers is not None:
+    if towers is not None and _PLAN is not None:
+        _PLAN.mark("towers_consumed")
+    elif towers is not None:
         towers.mark_consumed()               # static img_cls / gh have been read: the next replay may overwrite them
     if args.use_secla and not args.no_mapping and not cfg.only_image:
         enc = net.model.encoder
@@ -369,28 +382,54 @@ class PlannedTrainStep:
     kept, inputs are copied into static tensors before each replay.  world_size 1 (the DDP reducer launches its collectives
     from Python between backward nodes; it keeps the eager path)."""
 
-    def __init__(self, model, guide, optimizer, args: TrainArgs, example_batch, warmup=2):
+    def __init__(self, model, guide, optimizer, args: TrainArgs, example_batch, warmup=2, towers=None):
+        """towers: a FrozenTowerGraphs — the two frozen networks then stay hipGraph replays on their own streams, launched by the
+        host before every plan replay (so they overlap the previous step's tail), and the plan is split at two marks where the
+        host joins them (before the CoLaM loss) and releases their static outputs (after it)."""
+        global _PLAN
         from . import _lib
         if isinstance(model, DistributedDataParallel) and model.world > 1:
             raise RuntimeError("PlannedTrainStep: world_size 1 only (the reducer's bucket launches are host-side)")
         if streams.enabled() and not streams.explicit():
             raise RuntimeError("PlannedTrainStep needs explicit scheduling (VACNIC_EXPLICIT_STREAMS=0 is set)")
+        self.towers = towers
         self.static = {k: v.clone() for k, v in example_batch.items()}
         for _ in range(warmup):                              # eager: lazy buffers, kernel loading, allocator warm-up
-            train_step(model, guide, optimizer, self.static, args)
+            train_step(model, guide, optimizer, self.static, args, None, towers)
         torch.cuda.synchronize()
         self.stream = K._stream()
         self.pool = torch.cuda.MemPool()
+        self.marks = []
+        self._before()                                       # (host-side work of a step: not part of the plan)
         self.handle = int(_lib.lib.vacnic_plan_begin())
         if self.handle < 0:
             _lib.check(1)
+        _PLAN = self
         try:
             with torch.cuda.use_mem_pool(self.pool):
-                self.out4 = train_step(model, guide, optimizer, self.static, args)
+                self.out4 = train_step(model, guide, optimizer, self.static, args, None, towers)
         finally:
+            _PLAN = None
             _lib.check(_lib.lib.vacnic_plan_end(self.handle))
         torch.cuda.synchronize()
         self.commands = int(_lib.lib.vacnic_plan_size(self.handle))
+
+    def mark(self, what):
+        """called by forward_losses while recording: the host acts at this point of every replay."""
+        from . import _lib
+        self.marks.append((int(_lib.lib.vacnic_plan_mark()), what))
+        self._at(what)
+
+    def _before(self):
+        if self.towers is not None:
+            self.towers.launch_graphs(self.static)
+            torch.cuda.current_stream().wait_stream(streams.vit_stream())      # the student's encoder needs the image feature
+
+    def _at(self, what):
+        if what == "join_guide":
+            torch.cuda.current_stream().wait_stream(streams.aux_stream())
+        elif what == "towers_consumed":
+            self.towers.mark_consumed()
 
     def __call__(self, batch):
         from . import _lib
@@ -399,7 +438,13 @@ class PlannedTrainStep:
         for k, v in self.static.items():
             if batch[k] is not v:
                 v.copy_(batch[k], non_blocking=True)
-        _lib.call("vacnic_plan_replay", self.handle, 0, self.commands)
+        self._before()
+        pos = 0
+        for idx, what in self.marks:
+            _lib.call("vacnic_plan_replay", self.handle, pos, idx)
+            self._at(what)
+            pos = idx
+        _lib.call("vacnic_plan_replay", self.handle, pos, self.commands)
         return self.out4
 
     def close(self):
@@ -487,6 +532,25 @@ class FrozenTowerGraphs:
             tns.record_stream(aux)
         batch["img_tensor"].record_stream(vis)
         return src_mask, tgt_mask, tgt_in, ev_prep
+
+    def launch_graphs(self, batch, src_mask=None, tgt_in=None):
+        """both tower replays only (a launch plan computes the id masks itself): the guide's id inputs are derived here on its own
+        stream from the batch."""
+        aux, vis = streams.aux_stream(), streams.vit_stream()
+        main = torch.cuda.current_stream()
+        for s_ in (aux, vis):
+            s_.wait_stream(main)                 # the batch was refreshed in place on the compute stream
+            if self.consumed is not None:
+                s_.wait_event(self.consumed)
+        with torch.cuda.stream(vis):
+            self.img_s.copy_(batch["img_tensor"], non_blocking=True)
+            self.g_vit.replay()
+        if self.g_guide is not None:
+            with torch.cuda.stream(aux):
+                self.src_s.copy_(batch["article_ids"], non_blocking=True)
+                K.prep_ids_into(self.src_s, self.mask_s, None, self.pad)
+                K.prep_ids_into(batch["caption_ids"], None, self.tgtin_s, self.pad, self.start)
+                self.g_guide.replay()
 
     def mark_consumed(self):
         self.consumed = torch.cuda.Event()
