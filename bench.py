@@ -517,10 +517,13 @@ def main():
             graphed = None
             torch.cuda.synchronize()
     planned = None
+    host_idle_gpu = None
     if world == 1 and a.plan and graphed is None:
         try:
             planned = PlannedTrainStep(net, guide, opt, args, batches[0], warmup=max(1, a.warmup - 1), towers=towers)
+            t_h = time.perf_counter()
             planned(batches[1 % nb])
+            host_idle_gpu = time.perf_counter() - t_h      # enqueue time of one step with an idle GPU: no queue back-pressure
             torch.cuda.synchronize()
             log(f"launch plan recorded ({planned.commands} commands) and replayed once")
         except Exception as e:                      # never lose the measurement to a recording problem
@@ -529,7 +532,9 @@ def main():
             torch.cuda.synchronize()
     if graphed is None and planned is None:
         for i in range(a.warmup):
+            t_h = time.perf_counter()
             train_step(net, guide, opt, batches[i % nb], args, ready, towers)
+            host_idle_gpu = time.perf_counter() - t_h      # (the last warm-up step's: the GPU was idle when it began)
             torch.cuda.synchronize()
             log(f"warm-up step {i} done")
     if world > 1:
@@ -554,7 +559,7 @@ def main():
         elif graphed is not None:
             out4 = graphed(bt)
         elif planned is not None:
-            out4 = planned(bt)
+            out4 = planned(bt, ready)
         else:
             out4 = train_step(net, guide, opt, bt, args, ready, towers)
     timer.remove()
@@ -616,6 +621,10 @@ def main():
                                "eager multi-stream" + (", frozen towers as hipGraph replays" if towers is not None else "")),
                "host_enqueue_ms_per_step": round(host_dt / a.steps * 1e3, 2),
                "c_abi_calls_per_step": round(calls_per_step, 1), "host_cpu_ms_per_step": round(host_cpu * 1e3, 2),
+               # host_enqueue / host_cpu above include the time the launching thread spins on a full HIP queue (the host runs ~2 steps
+               # ahead of a GPU-bound step and is then throttled to the GPU's pace); this is the launch path's own cost: one step
+               # enqueued from an idle GPU (the last warm-up step)
+               "host_launch_path_ms_per_step": round(host_idle_gpu * 1e3, 2) if host_idle_gpu is not None else None,
                "per_rank_ms_per_step": per_rank_ms,
                "world_size_reported": dist.get_world_size() if world > 1 else 1,
                "dist_backend": (backend if world > 1 else None), "grad_transport": (a.grad_transport if world > 1 else None),

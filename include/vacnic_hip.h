@@ -128,6 +128,10 @@ typedef struct {
   int64_t ldq, ldk, ldv, ldo;
   int64_t bsq, bsk, bsv, bso;     /* batch strides in elements */
   int32_t causal; float scale;
+  /* attention-probability dropout, nn.functional.dropout(attn_weights, p=attention_dropout) of MFULL:546 (0.0 in bart-base/large):
+     p_drop in [0,1) quantised to 1/256; Philox keep bits from (seed ^ f(*seed_dev), batch, head, query, key), regenerated by
+     vacnic_attn_bwd from the same seed — the [B*H, Tq, Tk] mask is never stored.  lse stays the undropped log-sum-exp. */
+  float p_drop; uint64_t seed; const uint64_t* seed_dev;
 } vacnic_attn_fwd_args;
 int vacnic_attn_fwd(const vacnic_attn_fwd_args* a, void* stream);
 
@@ -141,6 +145,7 @@ typedef struct {
   int64_t bsq, bsk, bsv, bso;
   int64_t lddq, lddk, lddv, bsdq, bsdk, bsdv;
   int32_t causal; float scale;
+  float p_drop; uint64_t seed; const uint64_t* seed_dev;      /* as in the forward call */
 } vacnic_attn_bwd_args;
 int vacnic_attn_bwd(const vacnic_attn_bwd_args* a, void* stream);
 
@@ -157,6 +162,10 @@ typedef struct {
   const uint64_t* seed_dev;      /* optional device counter mixed into the seed (fresh masks under hipGraph replay) */
 } vacnic_add_ln_fwd_args;
 int vacnic_add_ln_fwd(const vacnic_add_ln_fwd_args* a, void* stream);
+/* out[i] = x[i] * keep_i / (1 - p) on a flat bf16 array (in place allowed; n % 8 == 0): nn.functional.dropout(act(fc1 x),
+ * p=activation_dropout) of the FFN blocks (MFULL:649,660,684,740,874).  Philox keep bits from (seed ^ f(*seed_dev), element
+ * index) exactly as in add_ln: backward calls it again on the gradient with the same seed, nothing is stored. */
+int vacnic_dropout_bf16(const void* x, void* out, int64_t n, float p_drop, uint64_t seed, const uint64_t* seed_dev, void* stream);
 
 /* backward: recomputes h = residual + dropout(x) from the saved INPUTS (x, residual) and the saved
  * mean/rstd; writes dresidual (= d h) and dx (= d h * keep/(1-p)); either may be NULL.  With

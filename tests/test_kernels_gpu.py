@@ -368,6 +368,100 @@ def test_add_ln(K, R, D):
     close(out2, torch.nn.functional.layer_norm(x.float(), (D,), g, b, 1e-5), 1e-2, 1e-2, "plain LN")
 
 
+def _recover_attn_mask(K, q, k, B, H, Tq, Tk, p, seed, key_mask=None, causal=False):
+    """(P o M / (1 - p_q)) of the kernel itself: with V = a one-hot window of 64 keys the output row of head h IS the dropped
+    probability row restricted to that window."""
+    pm = torch.zeros(B, H, Tq, Tk)
+    for w0 in range(0, Tk, 64):
+        v = torch.zeros(B, Tk, H * 64, device="cuda", dtype=torch.bfloat16)
+        n = min(64, Tk - w0)
+        for h in range(H):
+            v[:, w0:w0 + n, h * 64:h * 64 + n] = torch.eye(n, device="cuda", dtype=torch.bfloat16)
+        o, _ = K.attn_fwd(q, k, v, B, H, Tq, Tk, key_mask=key_mask, causal=causal, p_drop=p, seed=seed)
+        pm[:, :, :, w0:w0 + n] = o.float().view(B, Tq, H, 64).permute(0, 2, 1, 3)[..., :n].cpu()
+    return pm
+
+
+@pytest.mark.parametrize("Tq,Tk,causal", [(64, 64, False), (100, 200, False), (72, 72, True)])
+def test_attention_probability_dropout(K, Tq, Tk, causal):
+    """attention_dropout > 0 (MFULL:546): P -> P o M / (1 - p) AFTER the softmax, mask from Philox(seed, b, h, q, k) regenerated by
+    the two backward kernels.  The mask is read off the kernel (one-hot values), checked for its rate, independence of V and
+    seed dependence; forward and all three gradients are then compared with torch autograd using that mask."""
+    B, H, p, seed = 2, 2, 0.25, 777
+    q = rnd(B, Tq, H * 64, scale=0.7, seed=1); k = rnd(B, Tk, H * 64, scale=0.7, seed=2); v = rnd(B, Tk, H * 64, seed=3)
+    km = torch.ones(B, Tk, dtype=torch.uint8); km[1, Tk - 7:] = 0; km = km.cuda()
+    pm = _recover_attn_mask(K, q, k, B, H, Tq, Tk, p, seed, key_mask=km, causal=causal)
+    qf, kf, vf = (t.float().cpu().view(B, -1, H, 64).transpose(1, 2) for t in (q, k, v))
+    sc = qf @ kf.transpose(-1, -2) * 0.125
+    sc = sc + (1 - km.cpu().float())[:, None, None, :] * torch.finfo(torch.float32).min
+    if causal:
+        sc = sc + torch.triu(torch.full((Tq, Tk), torch.finfo(torch.float32).min), 1)
+    P = torch.softmax(sc, -1)
+    big = P > 1e-3                                            # where a dropped entry is distinguishable from a tiny probability
+    keep = pm > 0
+    p_q = round(p * 256) / 256
+    frac = keep[big].float().mean().item()
+    assert abs(frac - (1 - p_q)) < 0.03, f"keep fraction {frac} vs {1 - p_q}"
+    M = torch.where(keep | ~big, torch.full_like(P, 1 / (1 - p_q)), torch.zeros_like(P))
+    assert ((pm - P * M).abs()[big] < 2e-2 * (P * M)[big] + 2e-3).all(), "kept probabilities are P / (1 - p)"
+    # the kernel with real values == torch with that mask, forward and backward
+    qa, ka, va = (t.clone().requires_grad_(True) for t in (qf, kf, vf))
+    s2 = qa @ ka.transpose(-1, -2) * 0.125 + (1 - km.cpu().float())[:, None, None, :] * torch.finfo(torch.float32).min
+    if causal:
+        s2 = s2 + torch.triu(torch.full((Tq, Tk), torch.finfo(torch.float32).min), 1)
+    want = (torch.softmax(s2, -1) * M) @ va
+    out, lse = K.attn_fwd(q, k, v, B, H, Tq, Tk, key_mask=km, causal=causal, p_drop=p, seed=seed)
+    close(out.view(B, Tq, H, 64).transpose(1, 2).cpu(), want, 2e-2, 2e-2, "dropout forward")
+    close(lse.cpu(), torch.logsumexp(s2, -1), 1e-3, 1e-3, "lse is the undropped one")
+    dout = rnd(B, Tq, H * 64, seed=9)
+    want.backward(dout.float().cpu().view(B, Tq, H, 64).transpose(1, 2))
+    dq = torch.empty_like(q); dk = torch.empty_like(k); dv = torch.empty_like(v)
+    K.attn_bwd(q, k, v, out, dout, lse, dq, dk, dv, B, H, Tq, Tk, key_mask=km, causal=causal, p_drop=p, seed=seed)
+    for name, got, ref in (("dq", dq, qa.grad), ("dk", dk, ka.grad), ("dv", dv, va.grad)):
+        g = got.float().cpu().view(B, -1, H, 64).transpose(1, 2)
+        assert ((g - ref).norm() / ref.norm()).item() < 2e-2, (name, ((g - ref).norm() / ref.norm()).item())
+    out2, _ = K.attn_fwd(q, k, v, B, H, Tq, Tk, key_mask=km, causal=causal, p_drop=p, seed=seed)
+    assert torch.equal(out, out2), "same seed -> same mask"
+    out3, _ = K.attn_fwd(q, k, v, B, H, Tq, Tk, key_mask=km, causal=causal, p_drop=p, seed=seed + 1)
+    assert not torch.equal(out, out3)
+    out0, _ = K.attn_fwd(q, k, v, B, H, Tq, Tk, key_mask=km, causal=causal, p_drop=0.0, seed=seed)
+    outn, _ = K.attn_fwd(q, k, v, B, H, Tq, Tk, key_mask=km, causal=causal)
+    assert torch.equal(out0, outn), "p = 0 is the plain kernel"
+
+
+def test_activation_dropout_kernel_and_mlp2(K):
+    """activation_dropout > 0 (MFULL:649,740,874): in-place Philox dropout of act(fc1 x); the same call on the gradient is its
+    backward.  Kernel: rate, scaling, determinism; Mlp2Fn: forward / input gradient against torch with the recovered mask."""
+    from vacnic_amd import ops
+    x = rnd(512, 1024, seed=1)
+    y = K.dropout_(x.clone(), 0.2, 99)
+    keep = y.float() != 0
+    assert abs(keep.float().mean().item() - 0.8) < 0.01
+    close(y.float()[keep], (x.float() / 0.8)[keep], 1e-2, 1e-3, "kept values scaled by 1 / (1 - p)")
+    assert torch.equal(y, K.dropout_(x.clone(), 0.2, 99)) and not torch.equal(y, K.dropout_(x.clone(), 0.2, 100))
+    M, d, F = 96, 256, 512
+    w1 = rnd(F, d, scale=0.05, seed=2); b1 = rnd(F, dtype=torch.float32, seed=3) * 0.1
+    w2 = rnd(d, F, scale=0.05, seed=4); b2 = rnd(d, dtype=torch.float32, seed=5) * 0.1
+    s1 = ops.LinearSpec(w1, b1, torch.zeros(F, d, device="cuda"), torch.zeros(F, device="cuda"))
+    s2 = ops.LinearSpec(w2, b2, torch.zeros(d, F, device="cuda"), torch.zeros(d, device="cuda"))
+    xin = rnd(M, d, seed=6).requires_grad_(True)
+    anchor = torch.zeros(1, device="cuda", requires_grad=True)
+    ops.Rng.device_counter().zero_()
+    out = ops.Mlp2Fn.apply(xin, anchor, s1, s2, "gelu", True, False, 0.3, 4242)
+    dout = rnd(M, d, seed=7)
+    out.backward(dout)
+    ops.flush_wgrads()
+    # the mask of the hidden activations: the same kernel call on an array of ones
+    mask = K.dropout_(torch.ones(M, F, device="cuda", dtype=torch.bfloat16), 0.3, 4242, ops.Rng.device_counter()).float()
+    xr = xin.detach().float().requires_grad_(True)
+    h = torch.nn.functional.gelu(xr @ w1.float().t() + b1) * mask
+    ref = h @ w2.float().t() + b2
+    close(out, ref, 2e-2, 2e-2, "mlp2 with activation dropout")
+    ref.backward(dout.float())
+    assert ((xin.grad.float() - xr.grad).norm() / xr.grad.norm()).item() < 2e-2
+    assert ((s2.wgrad - (dout.float().t() @ h.detach())).norm() / (dout.float().t() @ h.detach()).norm()).item() < 2e-2, "fc2's weight gradient sees the dropped activations"
+
+
 def test_add_ln_dropout_consistency(K):
     R, D, p = 256, 1024, 0.1
     x = rnd(R, D, seed=1); res = torch.zeros(R, D, device="cuda", dtype=torch.bfloat16)

@@ -822,6 +822,50 @@ def test_whole_step_hipgraph_replays_like_eager():
         streams.enable(False)
 
 
+def test_attention_and_activation_dropout_on_the_operator_surface():
+    """config.attention_dropout / activation_dropout > 0 (MFULL:546,649,740,874; 0.0 in the hub configs, but part of the
+    reference's surface): eval mode ignores them (same losses as the p = 0 model to the bit), training mode applies Philox masks
+    that are reproducible from the seed, change with it, and are regenerated in backward (a second backward-capable step gives
+    the same gradients); the whole step also trains (finite, decreasing loss) with all three dropouts on."""
+    from vacnic_amd import ops, synthetic
+    from vacnic_amd.config import ClipVisionConfig
+    from vacnic_amd.training import FusedAdamW, TrainArgs, build_models, forward_losses, to_device, train_step
+    vcfg = ClipVisionConfig(width=768, layers=1, patch_size=16, image_size=32, output_dim=64)
+    batch = to_device(synthetic.make_batch(small_cfg(), 3, S=40, T=12, F=3, seed=5, image_size=32), "cuda")
+    args = TrainArgs(num_training_steps=50, lr_bart=2e-4)
+
+    def build(**kw):
+        cfg = small_cfg(encoder_layers=1, decoder_layers=1, **kw)
+        return build_models(cfg, vcfg, init="synthetic", seed=0)
+    m0, g0, _ = build(dropout=0.0)
+    m1, g1, _ = build(dropout=0.0, attention_dropout=0.2, activation_dropout=0.3)
+    m0.eval(); m1.eval()
+    with torch.no_grad():
+        l0 = forward_losses(m0, g0, batch, args)[1]
+        l1 = forward_losses(m1, g1, batch, args)[1]
+    assert torch.equal(l0, l1), "eval mode: dropout probabilities have no effect"
+    m1.train()
+
+    def grads(seed):
+        ops.Rng.manual_seed(seed); ops.Rng.device_counter().zero_()
+        m1.arena.grad.zero_()
+        total, out4, _ = forward_losses(m1, g1, batch, args)
+        total.backward()
+        ops.flush_wgrads()
+        torch.cuda.synchronize()
+        return out4.clone(), m1.arena.grad.clone()
+    la, ga = grads(11)
+    lb, gb = grads(11)
+    lc, _ = grads(12)
+    assert torch.isfinite(la).all() and not torch.equal(la[1], l1[1]), "training mode applies the masks"
+    assert torch.allclose(la, lb, rtol=1e-5) and rel(gb, ga) < 1e-3, "same seed -> same masks in forward AND backward"
+    assert not torch.allclose(la, lc, rtol=1e-6), "another seed -> other masks"
+    m2, g2, _ = build(dropout=0.1, attention_dropout=0.1, activation_dropout=0.1)
+    opt = FusedAdamW(m2.arena, lr=args.lr_bart, num_warmup_steps=1, num_training_steps=50)
+    losses = [train_step(m2, g2, opt, batch, args)[1].item() for _ in range(8)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
 @pytest.mark.parametrize("side_streams", [True, False, "tower_graphs"])
 def test_planned_step_replays_like_eager(side_streams):
     """launch plans (include/vacnic_hip.h): the full step recorded once through the C-ABI — kernels of every stream and the

@@ -51,7 +51,7 @@ AttnFwdArgs = _struct("vacnic_attn_fwd_args", [
     ("B", i64), ("H", i64), ("Tq", i64), ("Tk", i64),
     ("ldq", i64), ("ldk", i64), ("ldv", i64), ("ldo", i64),
     ("bsq", i64), ("bsk", i64), ("bsv", i64), ("bso", i64),
-    ("causal", i32), ("scale", f32)])
+    ("causal", i32), ("scale", f32), ("p_drop", f32), ("seed", u64), ("seed_dev", vp)])
 
 AttnBwdArgs = _struct("vacnic_attn_bwd_args", [
     ("q", vp), ("k", vp), ("v", vp), ("out", vp), ("dout", vp), ("lse", vp), ("delta", vp),
@@ -60,7 +60,7 @@ AttnBwdArgs = _struct("vacnic_attn_bwd_args", [
     ("ldq", i64), ("ldk", i64), ("ldv", i64), ("ldo", i64),
     ("bsq", i64), ("bsk", i64), ("bsv", i64), ("bso", i64),
     ("lddq", i64), ("lddk", i64), ("lddv", i64), ("bsdq", i64), ("bsdk", i64), ("bsdv", i64),
-    ("causal", i32), ("scale", f32)])
+    ("causal", i32), ("scale", f32), ("p_drop", f32), ("seed", u64), ("seed_dev", vp)])
 
 AddLnFwdArgs = _struct("vacnic_add_ln_fwd_args", [
     ("x", vp), ("residual", vp), ("gamma", vp), ("beta", vp), ("out", vp), ("mean", vp), ("rstd", vp),
@@ -161,6 +161,7 @@ _PLAIN_FNS = {
     "vacnic_prep_ids": [vp, vp, vp, i64, i64, i64, i64, vp],
     "vacnic_face_mask": [vp, vp, i64, i64, vp],
     "vacnic_cat2_u8": [vp, vp, vp, i64, i64, i64, vp],
+    "vacnic_dropout_bf16": [vp, vp, i64, f32, u64, vp, vp],
     "vacnic_argmax_rows": [vp, vp, i64, i64, i64, i32, vp],
     "vacnic_bias_grad": [vp, vp, i64, i64, i64, vp],
     "vacnic_add_bf16": [vp, vp, vp, i64, vp],

@@ -85,7 +85,44 @@ struct AttnP {
   int ldq, ldk, ldv, ldo, lddq, lddk, lddv;
   long bsq, bsk, bsv, bso, bsdq, bsdk, bsdv;
   int causal; float scale;
+  // attention-probability dropout (MFULL:546): keep iff byte >= drop_thr (p quantised to 1/256), kept entries scaled by drop_inv
+  unsigned drop_thr; float drop_inv; unsigned long long drop_seed; const unsigned long long* drop_seed_dev;
 };
+
+// Dropout mask of the probabilities: ONE Philox4x32-10 block per 4 x 4 patch of the [Tq, Tk] matrix of a (batch, head) — 16
+// random bytes, byte (qi, ki) of the patch in word qi, bits 8*ki.  A lane that holds 4 consecutive KEYS of one query (forward,
+// dQ) takes one word of its patch, a lane that holds 4 consecutive QUERIES of one key (dK/dV) one byte of each word: every
+// kernel regenerates the same mask with one block per 4 probabilities, and nothing is stored.
+struct DropCtx { unsigned long long seed; unsigned long long bh_base; unsigned pk_per_row; unsigned thr; float inv; };
+
+__device__ __forceinline__ DropCtx drop_ctx(const AttnP& p, int b, int hd) {
+  DropCtx d;
+  d.seed = p.drop_seed_dev ? p.drop_seed ^ (*p.drop_seed_dev * 0x9E3779B97F4A7C15ull) : p.drop_seed;      // norm.hip's mix_seed
+  d.pk_per_row = (unsigned)((p.Tk + 3) >> 2);
+  d.bh_base = ((unsigned long long)b * p.H + hd) * (unsigned long long)((p.Tq + 3) >> 2) * d.pk_per_row;
+  d.thr = p.drop_thr; d.inv = p.drop_inv;
+  return d;
+}
+__device__ __forceinline__ void drop_patch(const DropCtx& d, int q, int k, uint32_t w[4]) {
+  const unsigned long long idx = d.bh_base + (unsigned long long)(q >> 2) * d.pk_per_row + (unsigned)(k >> 2);
+  philox4x32((uint32_t)idx, (uint32_t)(idx >> 32), 0x41545444u, 0u, (uint32_t)d.seed, (uint32_t)(d.seed >> 32), w);
+}
+// keep factors of the 4 keys k0 .. k0+3 (k0 % 4 == 0) of query q
+__device__ __forceinline__ void drop_keys4(const DropCtx& d, int q, int k0, float m[4]) {
+  uint32_t w[4];
+  drop_patch(d, q, k0, w);
+  const uint32_t x = w[q & 3];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) m[e] = ((x >> (8 * e)) & 0xffu) >= d.thr ? d.inv : 0.f;
+}
+// keep factors of the 4 queries q0 .. q0+3 (q0 % 4 == 0) for key k
+__device__ __forceinline__ void drop_queries4(const DropCtx& d, int q0, int k, float m[4]) {
+  uint32_t w[4];
+  drop_patch(d, q0, k, w);
+  const int sh = 8 * (k & 3);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) m[e] = ((w[e] >> sh) & 0xffu) >= d.thr ? d.inv : 0.f;
+}
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const bf16_t* base, int rows, int ld) {
   const unsigned bytes = rows > 0 ? ((unsigned)(rows - 1) * (unsigned)ld + 64u) * 2u : 0u;
@@ -118,7 +155,7 @@ __device__ __forceinline__ void xcd_order(int nblk, int H, int nbh, int& blk, in
 // =================================================================================================
 // forward:  S^T = K Q^T (keys in registers, query on the lane) -> online softmax -> O^T = V^T P^T
 // =================================================================================================
-template <bool CAUSAL>
+template <bool CAUSAL, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -160,6 +197,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   o[0] = (f32x16)(0.f); o[1] = (f32x16)(0.f);
   float m_run = -INFINITY, l_run = 0.f;
   const int qidx = q0 + ql;
+  DropCtx dctx;
+  if (DROP) dctx = drop_ctx(p, b, hd);
 
   for (int t = 0; t < ntile; ++t) {
     const int cur = t & 1;
@@ -215,6 +254,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
       }
     l_run = l_run * alpha + psum;
     m_run = m_new;
+    if (DROP) {          // the normaliser sums the undropped probabilities (softmax first, dropout second: MFULL:534,546)
+#pragma unroll
+      for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float mk[4];
+          drop_keys4(dctx, qidx, t * 64 + kb2 * 32 + 8 * g + 4 * hh, mk);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s[kb2][4 * g + e] *= mk[e];
+        }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
     // ---- O^T[hd][q] += V^T P^T
@@ -290,6 +340,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 //   dV^T[d][k] += dO^T P    (A = dO^T via tr-read, B = P accumulator)
 //   dK^T[d][k] += Q^T dS    (A = Q^T  via tr-read, B = dS accumulator)
 // =================================================================================================
+template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -330,6 +381,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnP p) {
 
   f32x16 dk[2], dv[2];
   dk[0] = (f32x16)(0.f); dk[1] = (f32x16)(0.f); dv[0] = (f32x16)(0.f); dv[1] = (f32x16)(0.f);
+  DropCtx dctx;
+  if (DROP) dctx = drop_ctx(p, b, hd);
 
   auto load_stat = [&](int t) -> float {
     float v = 0.f;
@@ -377,13 +430,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnP p) {
         const int ql0 = qb2 * 32 + 8 * g + 4 * hh;
         const f32x4 l4 = *(const f32x4*)(st + ql0);
         const f32x4 d4 = *(const f32x4*)(st + 64 + ql0);
+        float mq[4] = {1.f, 1.f, 1.f, 1.f};
+        if (DROP) drop_queries4(dctx, t * 64 + ql0, kidx, mq);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float v = s[4 * g + e] * p.scale + kbias;
           if (p.causal && kidx > (t * 64 + ql0 + e)) v += FMIN;
           const float pe = __expf(v - l4[e]);
-          s[4 * g + e] = pe;
-          dp[4 * g + e] = pe * (dp[4 * g + e] - d4[e]) * p.scale;
+          s[4 * g + e] = DROP ? pe * mq[e] : pe;                                   // dV = (P o M)^T dO
+          dp[4 * g + e] = pe * ((DROP ? dp[4 * g + e] * mq[e] : dp[4 * g + e]) - d4[e]) * p.scale;    // dS = P o (dP o M - delta)
         }
       }
 #pragma unroll
@@ -418,6 +473,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnP p) {
 // dQ: wave owns 32 queries (on the lane); sweeps 64-key tiles of K and V.
 //   S^T[k][q]  = K Q^T ; dP^T[k][q] = V dO^T ; dQ^T[d][q] += K^T dS^T (A = K^T via tr-read)
 // =================================================================================================
+template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -459,6 +515,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
   }
   f32x16 dq[2];
   dq[0] = (f32x16)(0.f); dq[1] = (f32x16)(0.f);
+  DropCtx dctx;
+  if (DROP) dctx = drop_ctx(p, b, hd);
 
   for (int t = 0; t < ntile; ++t) {
     const int cur = t & 1;
@@ -485,12 +543,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
       for (int g = 0; g < 4; ++g) {
         const int kbase = t * 64 + kb2 * 32 + 8 * g + 4 * hh;
         const f32x4 bias = *(const f32x4*)(kbias + kbase);
+        float mk[4] = {1.f, 1.f, 1.f, 1.f};
+        if (DROP) drop_keys4(dctx, qidx, kbase, mk);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float v = s[4 * g + e] * p.scale + bias[e];
           if (p.causal && (kbase + e) > qidx) v += FMIN;
           const float pe = __expf(v - lse_q);
-          dp[4 * g + e] = pe * (dp[4 * g + e] - delta_q) * p.scale;
+          dp[4 * g + e] = pe * ((DROP ? dp[4 * g + e] * mk[e] : dp[4 * g + e]) - delta_q) * p.scale;
         }
       }
 #pragma unroll
@@ -513,6 +573,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
         *(u32x2*)(drow + hb * 32 + 8 * g + 4 * hh) = a;
       }
   }
+}
+
+// p in [0, 1): quantised to 1/256 (the kept probabilities are scaled by 1 / (1 - round(256 p) / 256), so the estimate stays unbiased)
+int set_dropout(AttnP& p, float p_drop, uint64_t seed, const uint64_t* seed_dev, const char* who) {
+  if (!(p_drop >= 0.f && p_drop < 1.f)) { vacnic_set_error("%s: p_drop must be in [0, 1)", who); return VACNIC_BAD_SHAPE; }
+  unsigned thr = (unsigned)(p_drop * 256.f + 0.5f);
+  if (thr > 255) thr = 255;
+  p.drop_thr = thr;
+  p.drop_inv = 256.f / (256.f - (float)thr);
+  p.drop_seed = seed; p.drop_seed_dev = (const unsigned long long*)seed_dev;
+  return VACNIC_OK;
 }
 
 int check_common(int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
@@ -674,7 +745,8 @@ extern "C" int vacnic_attn_fwd(const vacnic_attn_fwd_args* a, void* stream) {
   p.ldq = (int)a->ldq; p.ldk = (int)a->ldk; p.ldv = (int)a->ldv; p.ldo = (int)a->ldo;
   p.bsq = a->bsq; p.bsk = a->bsk; p.bsv = a->bsv; p.bso = a->bso;
   p.causal = a->causal; p.scale = a->scale;
-  if (p.Tq == 1 && !p.causal && p.Tk <= 16384) {      // decoder step: one wave per (row, head)
+  if (int e = set_dropout(p, a->p_drop, a->seed, a->seed_dev, "attn_fwd")) return e;
+  if (p.Tq == 1 && !p.causal && p.Tk <= 16384 && !p.drop_thr) {      // decoder step (inference): one wave per (row, head)
     if (p.Tk >= 256) hipLaunchKernelGGL(attn_decode_kernel<4>, dim3(p.H, p.B), dim3(256), (size_t)(p.Tk + 4 * 64 + 8) * 4, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(attn_decode_kernel<1>, dim3(p.H, p.B), dim3(64), (size_t)p.Tk * 4, (hipStream_t)stream, p);
     VLAUNCH_CHECK();
@@ -682,8 +754,15 @@ extern "C" int vacnic_attn_fwd(const vacnic_attn_fwd_args* a, void* stream) {
   }
   const int Tk_pad = (p.Tk + 63) & ~63;
   dim3 grid((unsigned)(((p.Tq + 127) / 128) * p.H * p.B));
-  if (p.causal) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 4 * TILE_B + Tk_pad * 4, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 4 * TILE_B + Tk_pad * 4, (hipStream_t)stream, p);
+  const size_t lds = 4 * TILE_B + Tk_pad * 4;
+  hipStream_t st = (hipStream_t)stream;
+  if (p.drop_thr) {
+    if (p.causal) hipLaunchKernelGGL((attn_fwd_kernel<true, true>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((attn_fwd_kernel<false, true>), grid, dim3(256), lds, st, p);
+  } else {
+    if (p.causal) hipLaunchKernelGGL((attn_fwd_kernel<true, false>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((attn_fwd_kernel<false, false>), grid, dim3(256), lds, st, p);
+  }
   VLAUNCH_CHECK();
   return VACNIC_OK;
 }
@@ -706,15 +785,19 @@ extern "C" int vacnic_attn_bwd(const vacnic_attn_bwd_args* a, void* stream) {
   p.bsq = a->bsq; p.bsk = a->bsk; p.bsv = a->bsv; p.bso = a->bso;
   p.bsdq = a->bsdq; p.bsdk = a->bsdk; p.bsdv = a->bsdv;
   p.causal = a->causal; p.scale = a->scale;
+  if (int e = set_dropout(p, a->p_drop, a->seed, a->seed_dev, "attn_bwd")) return e;
   hipStream_t s = (hipStream_t)stream;
   const long rows = (long)p.B * p.Tq;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const bf16_t*)a->out,
                      (const bf16_t*)a->dout, a->delta, p.B, p.H, p.Tq, p.ldo, (long)p.bso);
   VLAUNCH_CHECK();
   const int Tk_pad = (p.Tk + 63) & ~63;
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)(((p.Tk + 127) / 128) * p.H * p.B)), dim3(256), 4 * TILE_B + 2 * 128 * 4, s, p);
+  const dim3 gkv((unsigned)(((p.Tk + 127) / 128) * p.H * p.B)), gq((unsigned)(((p.Tq + 127) / 128) * p.H * p.B));
+  if (p.drop_thr) hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, gkv, dim3(256), 4 * TILE_B + 2 * 128 * 4, s, p);
+  else hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, gkv, dim3(256), 4 * TILE_B + 2 * 128 * 4, s, p);
   VLAUNCH_CHECK();
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(((p.Tq + 127) / 128) * p.H * p.B)), dim3(256), 4 * TILE_B + Tk_pad * 4, s, p);
+  if (p.drop_thr) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, gq, dim3(256), 4 * TILE_B + Tk_pad * 4, s, p);
+  else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, gq, dim3(256), 4 * TILE_B + Tk_pad * 4, s, p);
   VLAUNCH_CHECK();
   return VACNIC_OK;
 }

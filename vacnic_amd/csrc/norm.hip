@@ -470,6 +470,39 @@ static int check_d(int64_t D, const char* who) {
   return VACNIC_OK;
 }
 
+// out[i] = x[i] * keep_i / (1 - p): inverted dropout on a flat bf16 array (8 elements per thread, in place allowed).  The
+// activation dropout of the FFN blocks (MFULL:649,660,684,740,874): forward on act(fc1 x), backward on the gradient of the same
+// elements with the same (seed, element index) -> the same mask, nothing stored.
+namespace {
+__global__ __launch_bounds__(256) void dropout_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int64_t nchunk, float p_drop,
+                                                      uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nchunk) return;
+  seed = mix_seed(seed, seed_dev);
+  const uint32_t thr = dropout_threshold(p_drop);
+  const float inv_keep = 1.f / (1.f - p_drop);
+  float v[8], m[8];
+  load8(x + c * 8, v);
+  drop8(seed, (uint64_t)c * 8, thr, inv_keep, m);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] *= m[j];
+  store8(out + c * 8, v);
+}
+}  // namespace
+
+extern "C" int vacnic_dropout_bf16(const void* x, void* out, int64_t n, float p_drop, uint64_t seed, const uint64_t* seed_dev, void* stream) {
+  VPLAN_REC(vacnic_dropout_bf16, x, out, n, p_drop, seed, seed_dev, stream);
+  VCHECK(x && out && n >= 0, VACNIC_BAD_SHAPE, "dropout: null operand");
+  VCHECK((n & 7) == 0 && aligned16(x) && aligned16(out), VACNIC_MISALIGNED, "dropout: n %% 8 == 0 and 16-byte aligned arrays");
+  VCHECK(p_drop > 0.f && p_drop < 1.f, VACNIC_BAD_SHAPE, "dropout: 0 < p < 1");
+  if (n == 0) return VACNIC_OK;
+  const int64_t nchunk = n >> 3;
+  hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((nchunk + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)out,
+                     nchunk, p_drop, seed, seed_dev);
+  VLAUNCH_CHECK();
+  return VACNIC_OK;
+}
+
 extern "C" int vacnic_add_ln_fwd(const vacnic_add_ln_fwd_args* a, void* stream) {
   VPLAN_REC_STRUCT(vacnic_add_ln_fwd, a, stream);
   VCHECK(a && a->x && a->gamma && a->beta && a->out, VACNIC_BAD_SHAPE, "add_ln_fwd: null operand");

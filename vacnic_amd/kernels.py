@@ -165,18 +165,18 @@ def wgrad_group(jobs):
 
 
 # ------------------------------------------------------------------------------------------- attention
-def attn_fwd(q, k, v, B, H, Tq, Tk, key_mask=None, causal=False, scale=0.125, need_lse=True):
+def attn_fwd(q, k, v, B, H, Tq, Tk, key_mask=None, causal=False, scale=0.125, need_lse=True, p_drop=0.0, seed=0, seed_dev=None):
     """q/k/v: [B, T, >=H*64] views (unit inner stride); returns out [B,Tq,H*64] bf16 and lse [B,H,Tq]."""
     out = torch.empty((B, Tq, H * 64), device=q.device, dtype=BF16)
     lse = torch.empty((B, H, Tq), device=q.device, dtype=torch.float32) if need_lse else None
     call_struct("vacnic_attn_fwd", stream=_stream(), q=_p(q), k=_p(k), v=_p(v), out=_p(out), lse=_p(lse),
                 key_mask=_p(key_mask), B=B, H=H, Tq=Tq, Tk=Tk, ldq=q.stride(1), ldk=k.stride(1), ldv=v.stride(1),
                 ldo=out.stride(1), bsq=q.stride(0), bsk=k.stride(0), bsv=v.stride(0), bso=out.stride(0),
-                causal=int(causal), scale=scale)
+                causal=int(causal), scale=scale, p_drop=p_drop, seed=seed, seed_dev=_p(seed_dev))
     return out, lse
 
 
-def attn_bwd(q, k, v, out, dout, lse, dq, dk, dv, B, H, Tq, Tk, key_mask=None, causal=False, scale=0.125):
+def attn_bwd(q, k, v, out, dout, lse, dq, dk, dv, B, H, Tq, Tk, key_mask=None, causal=False, scale=0.125, p_drop=0.0, seed=0, seed_dev=None):
     delta = torch.empty((B, H, Tq), device=q.device, dtype=torch.float32)
     assert dout.stride() == out.stride()
     call_struct("vacnic_attn_bwd", stream=_stream(), q=_p(q), k=_p(k), v=_p(v), out=_p(out), dout=_p(dout), lse=_p(lse),
@@ -184,7 +184,8 @@ def attn_bwd(q, k, v, out, dout, lse, dq, dk, dv, B, H, Tq, Tk, key_mask=None, c
                 ldq=q.stride(1), ldk=k.stride(1), ldv=v.stride(1), ldo=out.stride(1),
                 bsq=q.stride(0), bsk=k.stride(0), bsv=v.stride(0), bso=out.stride(0),
                 lddq=dq.stride(1), lddk=dk.stride(1), lddv=dv.stride(1),
-                bsdq=dq.stride(0), bsdk=dk.stride(0), bsdv=dv.stride(0), causal=int(causal), scale=scale)
+                bsdq=dq.stride(0), bsdk=dk.stride(0), bsdv=dv.stride(0), causal=int(causal), scale=scale, p_drop=p_drop, seed=seed,
+                seed_dev=_p(seed_dev))
 
 
 # -------------------------------------------------------------------------------------------- LN family
@@ -219,6 +220,13 @@ def add_ln_bwd(dout, x, residual, gamma, mean, rstd, dgamma, dbeta, p_drop=0.0, 
                 mean=_p(mean), rstd=_p(rstd), dresidual=_p(dres), dx=_p(dx), dgamma=_p(dgamma), dbeta=_p(dbeta),
                 R=R, D=D, p_drop=p_drop, seed=seed, seed_dev=_p(seed_dev), partials=_p(part), partial_rows=prow)
     return dx, (dres if dres is not None else dx)
+
+
+def dropout_(x, p_drop, seed, seed_dev=None):
+    """in-place inverted dropout of a contiguous bf16 tensor (activation dropout; the same call on the gradient is its backward)."""
+    assert x.is_contiguous() and x.dtype == BF16
+    call("vacnic_dropout_bf16", _p(x), _p(x), x.numel(), float(p_drop), int(seed), _p(seed_dev), _stream())
+    return x
 
 
 def embed_ln_fwd(ids, embed16, pos16, gamma, beta, embed_scale=1.0, pos_offset=2, eps=1e-5, p_drop=0.0, seed=0, seed_dev=None):

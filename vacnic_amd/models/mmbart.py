@@ -95,8 +95,8 @@ class BartAttention(nn.Module):
             raise ValueError(f"embed_dim must be divisible by num_heads (got `embed_dim`: {embed_dim} and `num_heads`: {num_heads}).")
         if self.head_dim != 64:
             raise ValueError("the gfx950 attention kernels are built for head_dim 64 (bart-base/large, CLIP ViT)")
-        if dropout != 0.0:
-            raise NotImplementedError("attention_dropout > 0 (bart-base/large ship 0.0)")
+        if not 0.0 <= dropout < 1.0:
+            raise ValueError(f"attention dropout must be in [0, 1), got {dropout}")
         self.scaling = self.head_dim ** -0.5
         self.is_decoder = is_decoder
         self.k_proj = nn.Linear(embed_dim, embed_dim, bias=bias)
@@ -133,14 +133,14 @@ class BartAttention(nn.Module):
             kvq = lin(hidden_states, self.k_proj.weight, self.s_kvq)
             if skip:
                 kvq, res = kvq
-            ctx = ops.self_attention(kvq, key_mask, causal, H)
+            ctx = ops.self_attention(kvq, key_mask, causal, H, self.dropout, self.training)                 # MFULL:546
         else:
             q = lin(hidden_states, self.q_proj.weight, self.s_q)
             if skip:
                 q, res = q
             if kv is None:
                 kv = self.project_kv(key_value_states)
-            ctx = ops.cross_attention(q, kv, key_mask, H, bank, slot)
+            ctx = ops.cross_attention(q, kv, key_mask, H, bank, slot, self.dropout, self.training)
         out = ops.linear(ctx, self.out_proj.weight, self.s_out)
         return (out, res) if skip else out
 
@@ -160,8 +160,9 @@ class BartEncoderLayer(nn.Module):
         self.self_attn = BartAttention(d, H, dropout=config.attention_dropout)
         self.self_attn_layer_norm = nn.LayerNorm(d)
         self.dropout = config.dropout
-        if config.activation_function != "gelu" or config.activation_dropout != 0.0:
-            raise NotImplementedError("activation_function must be gelu with activation_dropout 0 (bart-base/large)")
+        if config.activation_function != "gelu":
+            raise NotImplementedError("activation_function must be gelu (bart-base/large)")
+        self.activation_dropout = config.activation_dropout              # MFULL:580 (0.0 in the hub configs)
         self.fc1 = nn.Linear(d, config.encoder_ffn_dim)
         self.fc2 = nn.Linear(config.encoder_ffn_dim, d)
         self.final_layer_norm = nn.LayerNorm(d)
@@ -225,7 +226,7 @@ class BartEncoderLayer(nn.Module):
                 branch_ctx = contextlib.nullcontext()
             with branch_ctx:
                 # img FFN (MFULL:647-653)
-                a, r = ops.mlp2_skip(hidden_states_img, self.fc1.weight, self.s_up, self.s_down)
+                a, r = ops.mlp2_skip(hidden_states_img, self.fc1.weight, self.s_up, self.s_down, p_act=self.activation_dropout, training=self.training)   # :649
                 hidden_states_img = self._ln(a, r, self.img_layer_norm)
                 if not self.only_image:
                     if not add_ner_ffn:
@@ -238,7 +239,7 @@ class BartEncoderLayer(nn.Module):
                         raise ValueError(f"Attention mask should be of size {(Bq, 1, Sq, n_kv)}, but is "
                                          f"torch.Size([{Bq}, 1, {Sq}, {n_mask}])")
                     # face FFN (:658-664)
-                    a, r = ops.mlp2_skip(hidden_states_face, self.fc1.weight, self.s_fup, self.s_fdown)
+                    a, r = ops.mlp2_skip(hidden_states_face, self.fc1.weight, self.s_fup, self.s_fdown, p_act=self.activation_dropout, training=self.training)   # :660
                     hidden_states_face = self._ln(a, r, self.face_layer_norm)
                     face_kv, face_out = ops.fork(hidden_states_face)
                     # names attend to [faces ; names] (:666-679) — no dropout on this branch in the reference
@@ -250,7 +251,7 @@ class BartEncoderLayer(nn.Module):
                     ner_p, ner_out = ops.fork(hidden_states_ner)
                     # name-prefix FFN on the FLAT view [B, d, N] (reshape, not transpose; :682-688)
                     B, N, d = ner_p.shape
-                    pre = ops.mlp2(ner_p.reshape(B, d, N), self.fc1.weight, self.s_nup, self.s_ndown)
+                    pre = ops.mlp2(ner_p.reshape(B, d, N), self.fc1.weight, self.s_nup, self.s_ndown, p_act=self.activation_dropout, training=self.training)   # :684
                     pre = pre.reshape(B, self.max_ner_type_len_gt, d)
                     pre = ops.add_ln(pre, None, self.ner_map_layer_norm.weight, self.ner_map_layer_norm.bias, self.dropout, self.training)
                     img_kv, img_out = ops.fork(hidden_states_img)
@@ -270,7 +271,7 @@ class BartEncoderLayer(nn.Module):
         else:
             a, r = self.self_attn(h, key_mask=key_mask, skip=True)
             h = self._ln(a, r, self.self_attn_layer_norm)                                          # :726-736
-        a, r = ops.mlp2_skip(h, self.fc1.weight, self.s_fc1, self.s_fc2)
+        a, r = ops.mlp2_skip(h, self.fc1.weight, self.s_fc1, self.s_fc2, p_act=self.activation_dropout, training=self.training)   # :740
         h = self._ln(a, r, self.final_layer_norm)                                                  # :738-744
         return h, hidden_states_face, hidden_states_ner, hidden_states_img
 
@@ -283,6 +284,7 @@ class BartDecoderLayer(nn.Module):
         d = self.embed_dim = config.d_model
         self.self_attn = BartAttention(d, config.decoder_attention_heads, dropout=config.attention_dropout, is_decoder=True)
         self.dropout = config.dropout
+        self.activation_dropout = config.activation_dropout              # MFULL:778
         self.self_attn_layer_norm = nn.LayerNorm(d)
         self.encoder_attn = BartAttention(d, config.decoder_attention_heads, dropout=config.attention_dropout, is_decoder=True, cross_only=True)
         self.encoder_attn_layer_norm = nn.LayerNorm(d)
@@ -301,7 +303,7 @@ class BartDecoderLayer(nn.Module):
         h = self._ln(a, r, self.self_attn_layer_norm)
         a, r = self.encoder_attn(h, key_value_states=encoder_hidden_states, key_mask=encoder_key_mask, kv=kv, skip=True, bank=bank, slot=slot)
         h = self._ln(a, r, self.encoder_attn_layer_norm)
-        a, r = ops.mlp2_skip(h, self.fc1.weight, self.s_fc1, self.s_fc2)
+        a, r = ops.mlp2_skip(h, self.fc1.weight, self.s_fc1, self.s_fc2, p_act=self.activation_dropout, training=self.training)   # MFULL:874
         return self._ln(a, r, self.final_layer_norm)
 
 

@@ -296,12 +296,13 @@ def linear_skip(x, anchor, spec):
 
 # --------------------------------------------------------------------------------------------- MLP2
 class Mlp2Fn(Function):
-    """y = W2 act(W1 x + b1) + b2 — every two-layer block on the path: text/img/face FFN (MFULL:647-664,
+    """y = W2 dropout(act(W1 x + b1), p_act) + b2 — every two-layer block on the path: text/img/face FFN (MFULL:647-664,
     738-741), name-prefix FFN on the flat view (:682-687), ClipCap prompt MLP (MFULL:111-123), ViT MLP.
-    The activation backward is fused into the dgrad GEMM epilogue (dact_src)."""
+    The activation backward is fused into the dgrad GEMM epilogue (dact_src).  p_act > 0 (config.activation_dropout; 0.0 in
+    bart-base/large): an in-place Philox dropout pass over the hidden activations, repeated on their gradient in backward."""
 
     @staticmethod
-    def forward(ctx, x, anchor, s1, s2, act, ge, skip=False):
+    def forward(ctx, x, anchor, s1, s2, act, ge, skip=False, p_act=0.0, seed=0):
         _tag(ctx)
         x2 = _c(x).view(-1, s1.K)
         M = x2.shape[0]
@@ -309,9 +310,12 @@ class Mlp2Fn(Function):
         u = torch.empty((M, s1.N), device=x.device, dtype=BF16) if need else None
         h = torch.empty((M, s1.N), device=x.device, dtype=BF16)
         K.gemm(x2, s1.w16, M, s1.N, s1.K, bias=s1.bias, out=h, ldw=s1.ldw, act=act, preact=u)
+        if p_act > 0.0:
+            K.dropout_(h, p_act, seed, Rng.device_counter())
         out = torch.empty(x.shape[:-1] + (s2.N,), device=x.device, dtype=BF16)
         K.gemm(h, s2.w16, M, s2.N, s2.K, bias=s2.bias, out=out, ldw=s2.ldw)
         ctx.s1, ctx.s2, ctx.act, ctx.M = s1, s2, act, M
+        ctx.p_act, ctx.seed = p_act, seed
         ctx.save_for_backward(x2, u, h)
         ddp.expect(need, s1.wgrad, s1.bgrad, s2.wgrad, s2.bgrad)
         if skip:
@@ -327,7 +331,9 @@ class Mlp2Fn(Function):
             dy2 = K.pad_cols(dy2, (s2.N + 7) // 8 * 8)
         du = torch.empty((M, s1.N), device=dy.device, dtype=BF16)
         K.gemm(dy2, s2.w16, M, s1.N, s2.N, out=du, ldx=dy2.stride(0), ldw=s2.ldw, w_kstrided=True, act=act, dact_src=u)
-        _wgrad(dy2, h, s2, M)
+        if ctx.p_act > 0.0:                            # the mask commutes with the elementwise act'(u) the epilogue applied
+            K.dropout_(du, ctx.p_act, ctx.seed, Rng.device_counter())
+        _wgrad(dy2, h, s2, M)                          # h is the DROPPED activation: what fc2 saw in forward
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, s1.K), device=dy.device, dtype=BF16)
@@ -335,18 +341,20 @@ class Mlp2Fn(Function):
                    residual=_c(dskip).view(M, s1.K) if dskip is not None else None)
             dx = dx.view(dy.shape[:-1] + (s1.K,))
         _wgrad(du, x2, s1, M)
-        return dx, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None, None
 
 
-def mlp2(x, anchor, s1, s2, act="gelu"):
-    return Mlp2Fn.apply(x, anchor, s1, s2, act, torch.is_grad_enabled(), False)
+def mlp2(x, anchor, s1, s2, act="gelu", p_act=0.0, training=False):
+    p = p_act if training else 0.0
+    return Mlp2Fn.apply(x, anchor, s1, s2, act, torch.is_grad_enabled(), False, p, Rng.next() if p > 0 else 0)
 
 
-def mlp2_skip(x, anchor, s1, s2, act="gelu"):
+def mlp2_skip(x, anchor, s1, s2, act="gelu", p_act=0.0, training=False):
     """(mlp2(x), x) — see linear_skip."""
     if not (torch.is_grad_enabled() and x.requires_grad):
-        return mlp2(x, anchor, s1, s2, act), x
-    return Mlp2Fn.apply(x, anchor, s1, s2, act, True, True)
+        return mlp2(x, anchor, s1, s2, act, p_act, training), x
+    p = p_act if training else 0.0
+    return Mlp2Fn.apply(x, anchor, s1, s2, act, True, True, p, Rng.next() if p > 0 else 0)
 
 
 class MlpChainFn(Function):
@@ -418,17 +426,20 @@ def mlp_chain(x, anchor, specs, act="tanh"):
 
 # ---------------------------------------------------------------------------------------- attention
 class SelfAttnFn(Function):
-    """kvq: [B,T,3d] fused projection output, column blocks [K | V | Q] (arena order k,v,q)."""
+    """kvq: [B,T,3d] fused projection output, column blocks [K | V | Q] (arena order k,v,q).  p_drop: attention-probability dropout
+    (MFULL:546), Philox mask regenerated in backward from the same seed."""
 
     @staticmethod
-    def forward(ctx, kvq, key_mask, causal, H, ge):
+    def forward(ctx, kvq, key_mask, causal, H, ge, p_drop=0.0, seed=0):
         _tag(ctx)
         B, T, d3 = kvq.shape
         d = d3 // 3
+        sd = Rng.device_counter() if p_drop > 0 else None
         out, lse = K.attn_fwd(kvq[..., 2 * d:], kvq[..., :d], kvq[..., d:2 * d], B, H, T, T, key_mask=key_mask,
-                              causal=causal, scale=0.125, need_lse=ge and any(ctx.needs_input_grad))
+                              causal=causal, scale=0.125, need_lse=ge and any(ctx.needs_input_grad), p_drop=p_drop, seed=seed, seed_dev=sd)
         ctx.cfg = (B, H, T, d, causal)
         ctx.key_mask = key_mask
+        ctx.drop = (p_drop, seed)
         ctx.save_for_backward(kvq, out, lse)
         return out
 
@@ -436,10 +447,12 @@ class SelfAttnFn(Function):
     def backward(ctx, dout):
         kvq, out, lse = ctx.saved_tensors
         B, H, T, d, causal = ctx.cfg
+        p_drop, seed = ctx.drop
         dkvq = torch.empty_like(kvq)
         K.attn_bwd(kvq[..., 2 * d:], kvq[..., :d], kvq[..., d:2 * d], out, _c(dout), lse, dkvq[..., 2 * d:], dkvq[..., :d],
-                   dkvq[..., d:2 * d], B, H, T, T, key_mask=ctx.key_mask, causal=causal, scale=0.125)
-        return dkvq, None, None, None, None
+                   dkvq[..., d:2 * d], B, H, T, T, key_mask=ctx.key_mask, causal=causal, scale=0.125, p_drop=p_drop, seed=seed,
+                   seed_dev=Rng.device_counter() if p_drop > 0 else None)
+        return dkvq, None, None, None, None, None, None
 
 
 class CrossAttnFn(Function):
@@ -447,15 +460,17 @@ class CrossAttnFn(Function):
     bank / slot: when kv is output `slot` of SplitKvFn, dK|dV are written straight into the bank's [B,Tk,L*2d] gradient buffer."""
 
     @staticmethod
-    def forward(ctx, q, kv, key_mask, H, ge, bank=None, slot=0):
+    def forward(ctx, q, kv, key_mask, H, ge, bank=None, slot=0, p_drop=0.0, seed=0):
         _tag(ctx)
         B, Tq, d = q.shape
         Tk = kv.shape[1]
+        sd = Rng.device_counter() if p_drop > 0 else None
         out, lse = K.attn_fwd(q, kv[..., :d], kv[..., d:], B, H, Tq, Tk, key_mask=key_mask, causal=False, scale=0.125,
-                              need_lse=ge and any(ctx.needs_input_grad))
+                              need_lse=ge and any(ctx.needs_input_grad), p_drop=p_drop, seed=seed, seed_dev=sd)
         ctx.cfg = (B, H, Tq, Tk, d)
         ctx.key_mask = key_mask
         ctx.bank, ctx.slot = bank, slot
+        ctx.drop = (p_drop, seed)
         ctx.save_for_backward(q, kv, out, lse)
         return out
 
@@ -463,14 +478,16 @@ class CrossAttnFn(Function):
     def backward(ctx, dout):
         q, kv, out, lse = ctx.saved_tensors
         B, H, Tq, Tk, d = ctx.cfg
+        p_drop, seed = ctx.drop
         dq = torch.empty_like(q)
         if ctx.bank is not None:
             dkv = ctx.bank.grad_slot(ctx.slot)
         else:
             dkv = torch.empty((B, Tk, 2 * d), device=kv.device, dtype=BF16)
         K.attn_bwd(q, kv[..., :d], kv[..., d:], out, _c(dout), lse, dq, dkv[..., :d], dkv[..., d:], B, H, Tq, Tk,
-                   key_mask=ctx.key_mask, causal=False, scale=0.125)
-        return dq, dkv, None, None, None, None, None
+                   key_mask=ctx.key_mask, causal=False, scale=0.125, p_drop=p_drop, seed=seed,
+                   seed_dev=Rng.device_counter() if p_drop > 0 else None)
+        return dq, dkv, None, None, None, None, None, None, None
 
 
 class KvBank:
@@ -523,12 +540,14 @@ def split_kv(kv_all, L):
     return list(SplitKvFn.apply(kv_all, bank)), bank
 
 
-def self_attention(kvq, key_mask, causal, H):
-    return SelfAttnFn.apply(kvq, key_mask, causal, H, torch.is_grad_enabled())
+def self_attention(kvq, key_mask, causal, H, p_drop=0.0, training=False):
+    p = p_drop if training else 0.0
+    return SelfAttnFn.apply(kvq, key_mask, causal, H, torch.is_grad_enabled(), p, Rng.next() if p > 0 else 0)
 
 
-def cross_attention(q, kv, key_mask, H, bank=None, slot=0):
-    return CrossAttnFn.apply(q, kv, key_mask, H, torch.is_grad_enabled(), bank, slot)
+def cross_attention(q, kv, key_mask, H, bank=None, slot=0, p_drop=0.0, training=False):
+    p = p_drop if training else 0.0
+    return CrossAttnFn.apply(q, kv, key_mask, H, torch.is_grad_enabled(), bank, slot, p, Rng.next() if p > 0 else 0)
 
 
 # -------------------------------------------------------------------------------------------- LN family

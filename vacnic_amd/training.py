@@ -420,9 +420,9 @@ class PlannedTrainStep:
         self.marks.append((int(_lib.lib.vacnic_plan_mark()), what))
         self._at(what)
 
-    def _before(self):
+    def _before(self, batch=None, ready=None):
         if self.towers is not None:
-            self.towers.launch_graphs(self.static)
+            self.towers.launch_graphs(batch if batch is not None else self.static, ready)
             torch.cuda.current_stream().wait_stream(streams.vit_stream())      # the student's encoder needs the image feature
 
     def _at(self, what):
@@ -431,14 +431,18 @@ class PlannedTrainStep:
         elif what == "towers_consumed":
             self.towers.mark_consumed()
 
-    def __call__(self, batch):
+    def __call__(self, batch, ready=None):
+        """ready: optional event after which `batch` is resident in HBM (the tower graphs then start on it instead of behind the
+        previous step on the compute stream, like train_step's `ready`)."""
         from . import _lib
         if K._stream() != self.stream:
             raise RuntimeError("PlannedTrainStep: replay on the stream the plan was recorded on")
+        self._before(batch, ready)
+        if ready is not None:
+            torch.cuda.current_stream().wait_event(ready)
         for k, v in self.static.items():
             if batch[k] is not v:
                 v.copy_(batch[k], non_blocking=True)
-        self._before()
         pos = 0
         for idx, what in self.marks:
             _lib.call("vacnic_plan_replay", self.handle, pos, idx)
@@ -533,13 +537,18 @@ class FrozenTowerGraphs:
         batch["img_tensor"].record_stream(vis)
         return src_mask, tgt_mask, tgt_in, ev_prep
 
-    def launch_graphs(self, batch, src_mask=None, tgt_in=None):
+    def launch_graphs(self, batch, ready=None):
         """both tower replays only (a launch plan computes the id masks itself): the guide's id inputs are derived here on its own
         stream from the batch."""
         aux, vis = streams.aux_stream(), streams.vit_stream()
         main = torch.cuda.current_stream()
         for s_ in (aux, vis):
-            s_.wait_stream(main)                 # the batch was refreshed in place on the compute stream
+            # the towers read the CALLER's batch (resident: `ready`, or ordered on the compute stream), not the plan's static copy,
+            # so they need not queue behind the previous step's tail on the compute stream
+            if ready is None:
+                s_.wait_stream(main)
+            else:
+                s_.wait_event(ready)
             if self.consumed is not None:
                 s_.wait_event(self.consumed)
         with torch.cuda.stream(vis):
