@@ -52,8 +52,9 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="replay the step as one captured hipGraph (world 1 only). Measured slower than "
                     "eager multi-stream launches while the step is GPU-bound (91.0 vs 86.2 ms: hipGraph runs the side-stream branches "
                     "less concurrently), so eager is the default")
-    ap.add_argument("--plan", action="store_true", help="replay the step as a recorded launch plan (vacnic_plan_replay: one C-ABI call per step, the "
-                    "eager multi-stream schedule re-issued from C++; world 1)")
+    ap.add_argument("--no-plan", action="store_true", help="world 1: issue every step from Python (eager) instead of replaying the recorded launch "
+                    "plan (vacnic_plan_replay: the same multi-stream schedule re-issued from C++, a handful of C-ABI calls per step). "
+                    "Same-box A/B: 68.4 vs 68.6 ms per step; launch path 7 vs 24 ms of host time per step")
     ap.add_argument("--mock-step", action="store_true", help=argparse.SUPPRESS)    # tests/test_bench_launch.py: launcher plumbing without a GPU
     return ap.parse_args()
 
@@ -174,20 +175,27 @@ def _cpu_leg(cfg, vcfg, B, S, T, threads, timed=3):
 def cpu_baseline(B, S, T):
     """the oracle (CPU restatement, torch fp32 + autograd) timed on this box's host cores — cfg1 (BART-base +
     ViT-B/32 only-image, the reference's CPU-runnable plumbing case) and cfg2 (the benchmarked model), batch 2, one warm-up
-    and the best of 3 timed steps each.  Reported beside the GPU number, never the target."""
+    and the best of the timed steps each.  Reported beside the GPU number, never the target.
+    Threads: §8d says all physical cores; the oracle's step is a chain of small-batch GEMMs and elementwise ops that stops
+    scaling at a few tens of threads, so cfg2 is timed at 16 threads (one GPU's CPU share of the host) AND at min(cores, 64);
+    `value` is the better of the two, `cores` the thread count it was measured with, both figures are in the record."""
     from vacnic_amd.config import bart_base_vit_b32, bart_large_vit_l14
     cores, cpu_model = _cpu_info()
-    threads = min(cores, 16)                     # the box's CPU share for one GPU; more threads only thrash
-    torch.set_num_threads(threads)
     cfg1, vcfg1 = bart_base_vit_b32()
-    log("  cfg1 (BART-base + ViT-B/32 only-image)")
-    v1 = _cpu_leg(cfg1, vcfg1, B, S, T, threads)
     cfg2, vcfg2 = bart_large_vit_l14()
-    log("  cfg2 (BART-large + ViT-L/14 full VACNIC)")
-    v2 = _cpu_leg(cfg2, vcfg2, B, S, T, threads)
-    return {"value": round(v2, 4), "unit": "samples/s", "cores": threads, "kind": "port", "cpu_model": cpu_model, "host_cores_visible": cores,
-            "sample": f"oracle (torch fp32 CPU, {threads} threads) full train step fwd+bwd+AdamW of configs[1] (BART-large + ViT-L/14 full "
-                      f"VACNIC), batch {B} (S={S}, T={T}), best of 3 timed steps after 1 warm-up",
+    runs = {}
+    for threads in sorted({min(cores, 16), min(cores, 64)}):
+        torch.set_num_threads(threads)
+        log(f"  cfg2 (BART-large + ViT-L/14 full VACNIC), {threads} threads")
+        runs[threads] = _cpu_leg(cfg2, vcfg2, B, S, T, threads, timed=3 if threads <= 16 else 2)
+    best = max(runs, key=runs.get)
+    torch.set_num_threads(best)
+    log(f"  cfg1 (BART-base + ViT-B/32 only-image), {best} threads")
+    v1 = _cpu_leg(cfg1, vcfg1, B, S, T, best, timed=2)
+    return {"value": round(runs[best], 4), "unit": "samples/s", "cores": best, "kind": "port", "cpu_model": cpu_model, "host_cores_visible": cores,
+            "by_threads": {str(k): round(v, 4) for k, v in runs.items()},
+            "sample": f"oracle (torch fp32 CPU, {best} threads) full train step fwd+bwd+AdamW of configs[1] (BART-large + ViT-L/14 full "
+                      f"VACNIC), batch {B} (S={S}, T={T}), best of the timed steps after 1 warm-up",
             "cfg1": {"value": round(v1, 4), "unit": "samples/s",
                      "sample": f"same protocol, configs[0] (BART-base + ViT-B/32 --only_image), batch {B} (S={S}, T={T})"}}
 
@@ -518,7 +526,7 @@ def main():
             torch.cuda.synchronize()
     planned = None
     host_idle_gpu = None
-    if world == 1 and a.plan and graphed is None:
+    if world == 1 and not a.no_plan and graphed is None:
         try:
             planned = PlannedTrainStep(net, guide, opt, args, batches[0], warmup=max(1, a.warmup - 1), towers=towers)
             t_h = time.perf_counter()
@@ -590,19 +598,25 @@ def main():
             ach = fl / sec / 1e12
             names = {"NN": "gemm_kernel<false,false> (forward Linear, X[M,K] W[N,K])", "NT": "gemm_kernel<false,true> (dgrad)",
                      "TT": "gemm_kernel<true,true> (wgrad)", "TN": "gemm_kernel<true,false>"}
-            traffic = None
-            try:        # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes of this same command
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_hbm_traffic.json")))["kernels"]
-                # gemm_kernel<BM, BN, WM, WN, BKT, NSTAGE, PIPE, XKS, WKS, CE>: the last three flags name the layout
-                tag = {"NN": ", false, false, false>", "NT": ", false, true, false>", "TT": ", true, true, false>", "TN": ", true, false, false>"}[kind]
-                sel = [v for k, v in pm.items() if "gemm_kernel" in k and tag in k]
-                if sel:
-                    traffic = round(sum(v["launches"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) for v in sel) / sum(v["launches"] for v in sel))
-            except Exception:
-                traffic = None
+            traffic, traffic_src = None, None
+            for prof in ("r3_pmc_hbm_traffic.json", "r2_pmc_hbm_traffic.json"):
+                try:        # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes of this same command
+                    pm = json.load(open(os.path.join(ROOT, "profiles", prof)))["kernels"]
+                    # gemm_kernel<BM, BN, WM, WN, BKT, NSTAGE, PIPE, XKS, WKS, CE>: the last three flags name the layout
+                    tag = {"NN": ", false, false, false>", "NT": ", false, true, false>", "TT": ", true, true, false>", "TN": ", true, false, false>"}[kind]
+                    sel = [v for k, v in pm.items() if "gemm_kernel" in k and tag in k]
+                    if sel:
+                        traffic = round(sum(v["launches"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) for v in sel) / sum(v["launches"] for v in sel))
+                        traffic_src = f"committed profile profiles/{prof} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not re-measured in this run)"
+                        break
+                except Exception:
+                    continue
+            # algorithmic bytes of the same launches: X[M,K] + W[N,K] read once, out[M,N] written once, bf16
+            alg = sum(2.0 * (m_ * k_ + n_ * k_ + m_ * n_) for kd, _, _, _, (m_, n_, k_) in timer.rec if kd == kind and n_ > 0) / max(n, 1)
             roof = {"bound": "mfma", "kernel": names[kind], "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                    "traffic_note": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r2_pmc_hbm_traffic.json)", "launches": n,
+                    "traffic_note": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
+                    "algorithmic_bytes": round(alg), "traffic_ratio": round(traffic / alg, 3) if traffic and alg else None, "launches": n,
                     "flop_per_launch": round(fl / n),
                     "avg_launch_us": round(sec / n * 1e6, 2),
                     "all_gemm": {k: {"TFLOP/s": round(v[0] / v[1] / 1e12, 1), "ms": round(v[1] * 1e3, 2), "launches": v[2]} for k, v in agg.items()}}
