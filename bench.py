@@ -76,7 +76,10 @@ class GemmTimer:
             out = timer.orig(x, w, M, N, Kd, **kw)
             e.record()
             kind = ("T" if kw.get("x_kstrided") else "N") + ("T" if kw.get("w_kstrided") else "N")
-            timer.rec.append((kind, 2.0 * M * N * Kd, s, e, (M, N, Kd)))
+            osz = 2 if kw.get("out_mode", 0) == 0 else 4
+            extra = sum(kw.get(k_) is not None for k_ in ("preact", "residual", "dact_src"))
+            alg = 2.0 * (M * Kd + N * Kd) + M * N * (osz * (2 if kw.get("out_mode", 0) == 2 else 1) + 2 * extra)
+            timer.rec.append((kind, 2.0 * M * N * Kd, s, e, (M, N, Kd), alg))
             return out
         K.gemm = timed
         self.orig_group = K.wgrad_group
@@ -87,7 +90,8 @@ class GemmTimer:
             timer.orig_group(jobs)
             e.record()
             fl = sum(2.0 * dy.shape[0] * dy.shape[1] * x.shape[1] for dy, x, _, _ in jobs)
-            timer.rec.append(("TT", fl, s, e, (len(jobs), -1, int(jobs[0][0].shape[0]))))
+            alg = sum(2.0 * dy.shape[0] * (dy.shape[1] + x.shape[1]) + 8.0 * dy.shape[1] * x.shape[1] for dy, x, _, _ in jobs)
+            timer.rec.append(("TT", fl, s, e, (len(jobs), -1, int(jobs[0][0].shape[0])), alg))
         K.wgrad_group = timed_group
 
     def remove(self):
@@ -98,7 +102,7 @@ class GemmTimer:
     def summary(self):
         agg = {}
         shapes = {}
-        for kind, fl, s, e, shp in self.rec:
+        for kind, fl, s, e, shp, _alg in self.rec:
             dt = s.elapsed_time(e) * 1e-3
             a = agg.setdefault(kind, [0.0, 0.0, 0])
             a[0] += fl; a[1] += dt; a[2] += 1
@@ -242,90 +246,63 @@ def _config5_generate(model, b, mask, nmask, cls, **kw):
                           name_ids=b["names_art_ids"], name_mask=nmask, add_ner_ffn=True, **kw)
 
 
-def config5_id_check(model, cfg, margin=40.0):
-    """Id check of configs[4]'s code path at FULL model size (12+12 layers, S=512): the persistent decoder-step kernel (R = 5
-    rows) against the kernel-per-op chain (VACNIC_DECODE_PER_OP=1), beam 5 / max_length 50 / length_penalty 2.0 / min_length 49.
-    A random-init model's next-token distribution is flat (top-2 margins below bf16 resolution), so two correct bf16
-    implementations need not agree on ids.  Like tests/golden's config-5 fixture (oracle/cfg5_fixture.py, same recipe) the check
-    therefore conditions the model first — temporarily, everything is restored afterwards: tied embedding x6, decoder fc2 x3,
-    and ONE planted 48-token caption (each chain token's embedding row
-    gets a component along the final hidden state that precedes it, sized to win by `margin` logit units; states from the
-    per-op decoder, teacher forced, a few rounds until the margins hold) — then runs both paths.
-    Returns {"ids_match_per_op", "ids_match_planted", "planted_margin_min", ...}."""
-    import numpy as np
+def config5_id_check(model, cfg):
+    """configs[4]'s code path at FULL model size (12+12 layers, S=512, R = 5 beam rows, 49 positions): the persistent decoder-step
+    kernel against the kernel-per-op chain (VACNIC_DECODE_PER_OP=1), on the weights the step just trained.
+      * `ids_match_per_op`: the two paths' generated captions (beam 5, max_length 50, length_penalty 2.0, min_length 49).  A
+        random-init model's next-token distribution is flat — top-2 margins below bf16 resolution — so two correct bf16 decoders
+        may part ways at a near-tie; identical ids on weights with trained-like margins is what
+        tests/test_model_gpu.py::test_config5_batch1_beam5_maxlen50_matches_reference_golden asserts (against the reference).
+      * the margin-independent statement, teacher forced: both decoders fed the same tokens and the same beam reorders for all
+        49 positions — largest logit difference, and whether the arg-max agrees wherever the per-op top-2 margin exceeds 4x that
+        difference."""
     from vacnic_amd import generate as Gn
     from vacnic_amd.models.clip_vit import extract_clip_img_feat
     b, mask, nmask = _config5_inputs(cfg, 4242, 0)
-    shared = model.model.shared.weight
-    # 12 decoder layers dilute the input token's share of the final state by themselves; fc2 x3 removes what is left of it
-    # (self-similarity 0.26 -> 0.00) without making the network a noise amplifier: measured with the oracle on a 12-layer decoder,
-    # bf16 rounding moves the token-specific part of the final state by 2.8 % (attention value/out scales of 1.5, which the 2-layer
-    # fixture uses, make that 12-27 % at this depth — two correct bf16 decoders then disagree on everything)
-    scaled = [(shared, 6.0)] + [(layer.fc2.weight, 3.0) for layer in model.model.decoder.layers]
-    saved = [p_.data.clone() for p_, _ in scaled]
-    chain = [2] + [int(t) for t in np.random.default_rng(7).permutation(np.arange(1000, 50000))[:48]]
     out = {"ids_match_per_op": None}
-    os.environ["VACNIC_DECODE_PER_OP"] = "1"
     try:
         with torch.no_grad():
-            for (p_, k) in scaled:
-                p_.data.mul_(k)
-            model.arena.refresh_shadow()
-            E32, E16 = shared.data, model.emb16_pad
-            E0 = E32[torch.tensor(chain[1:], device="cuda")].clone()
             cls = extract_clip_img_feat(model.clip_model, b["img_tensor"])[1]
+            os.environ["VACNIC_DECODE_PER_OP"] = "1"
+            model.__dict__.pop("_decode_sessions", None)
+            ids_per_op = _config5_generate(model, b, mask, nmask, cls, use_graphs=False).cpu()
+            os.environ["VACNIC_DECODE_PER_OP"] = "0"
+            model.__dict__.pop("_decode_sessions", None)
+            ids_step = _config5_generate(model, b, mask, nmask, cls, use_graphs=False).cpu()
+            ses = list(model._decode_sessions.values())
+            path = "decoder_step_slots" if ses and ses[0].dec.step_kernel and ses[0].dec.slots is not None else \
+                   "decoder_step_barrier" if ses and ses[0].dec.step_kernel else "per_op"
+            same = bool(ids_step.shape == ids_per_op.shape and torch.equal(ids_step, ids_per_op))
+            first = next((i for i in range(min(ids_step.shape[1], ids_per_op.shape[1])) if ids_step[0, i] != ids_per_op[0, i]), -1)
+            # teacher forced comparison
             enc_h = model.model.encoder(input_ids=b["article_ids"], attention_mask=mask, image_features=cls, name_ids=b["names_art_ids"],
                                         name_mask=nmask, face_features=b["face_emb"], face_mask=Gn.K.face_mask(b["face_emb"]),
                                         add_ner_ffn=True)["last_hidden_state"]
-            dec = Gn.CachedDecoder(model, 1, enc_h.shape[1], 50, reorders=False)
-
-            def sweep(plant, mu):
-                """teacher forced over the chain; returns (normalised states, smallest margin of a chain token over all others)."""
-                dec.begin(enc_h, mask, 1)
-                hs, worst = [], 1e30
-                for t in range(48):
-                    logits = dec.step(torch.tensor([[chain[t]]], device="cuda"), t)[0, :model.V]
-                    h = dec.last_hidden[0].float()
-                    hs.append(h / h.norm())
-                    want = chain[t + 1]
-                    others = logits.clone(); others[want] = -1e30
-                    worst = min(worst, float(logits[want] - others.max()))
-                    if plant:
-                        d = h / h.norm() - mu
-                        d = d / d.norm()
-                        E32[want] = E0[t] + d * ((others.max() + margin - E0[t] @ h) / (d @ h))
-                        E16[want] = E32[want].to(torch.bfloat16)
-                return torch.stack(hs), worst
-            mu = sweep(False, None)[0].mean(0)        # the direction all final states share (see oracle/cfg5_fixture.py)
-            worst = -1e30
-            for rnd in range(6):
-                sweep(True, mu)
-                worst = sweep(False, mu)[1]
-                log(f"  config-5 id check: planting round {rnd}, smallest margin {worst:.1f}")
-                if worst >= margin - 5.0:
-                    break
-        os.environ["VACNIC_DECODE_PER_OP"] = "1"
-        model.__dict__.pop("_decode_sessions", None)
-        ids_per_op = _config5_generate(model, b, mask, nmask, cls, use_graphs=False).cpu()
-        os.environ["VACNIC_DECODE_PER_OP"] = "0"
-        model.__dict__.pop("_decode_sessions", None)
-        ids_step = _config5_generate(model, b, mask, nmask, cls, use_graphs=False).cpu()
-        ses = list(model._decode_sessions.values())
-        path = "decoder_step_slots" if ses and ses[0].dec.step_kernel and ses[0].dec.slots is not None else \
-               "decoder_step_barrier" if ses and ses[0].dec.step_kernel else "per_op"
-        want = torch.tensor([chain + [2]])
-        out = {"ids_match_per_op": bool(ids_step.shape == ids_per_op.shape and torch.equal(ids_step, ids_per_op)),
-               "ids_match_planted": bool(ids_step.shape == want.shape and torch.equal(ids_step, want)),
-               "planted_margin_min": round(worst, 1), "default_path": path, "tokens": int(ids_step.shape[1]),
-               "first_tokens": {"planted": chain[:8], "step_kernel": ids_step[0, :8].tolist(), "per_op": ids_per_op[0, :8].tolist()},
-               "note": f"full-size model conditioned like tests/golden's config-5 fixture (temporary weight scales + one planted 48-token "
-                       f"caption, margin {margin:.0f} logit units), beam 5, max_length 50, lp 2.0, min_length 49"}
+            R, T = 5, 50
+            fast = Gn.CachedDecoder(model, R, enc_h.shape[1], T, reorders=True)
+            os.environ["VACNIC_DECODE_PER_OP"] = "1"
+            ref = Gn.CachedDecoder(model, R, enc_h.shape[1], T, reorders=True)
+            fast.begin(enc_h, mask, R); ref.begin(enc_h, mask, R)
+            g = torch.Generator().manual_seed(5)
+            worst, agree, decided = 0.0, 0, 0
+            for t in range(T - 1):
+                ids = torch.randint(3, cfg.vocab_size, (R, 1), generator=g).cuda()
+                if t > 0:
+                    src = torch.randint(0, R, (R,), generator=g).cuda()
+                    fast.reorder(src, t); ref.reorder(src, t)
+                la = fast.step(ids, t)[:, :model.V].clone(); lb = ref.step(ids, t)[:, :model.V]
+                err = float((la - lb).abs().max())
+                worst = max(worst, err)
+                top2 = lb.topk(2, dim=1).values
+                clear = (top2[:, 0] - top2[:, 1]) > 4 * max(err, 1e-6)
+                decided += int(clear.sum()); agree += int((la.argmax(1) == lb.argmax(1))[clear].sum())
+            fast.check_step_kernel()
+        out = {"ids_match_per_op": same, "first_differing_position": first, "default_path": path, "tokens": int(ids_step.shape[1]),
+               "teacher_forced_max_logit_diff": round(worst, 4), "teacher_forced_clear_decisions": decided,
+               "teacher_forced_clear_decisions_agree": agree,
+               "note": "full-size model, benchmark weights; generation ids of step kernel vs per-op chain + both fed the same 49 x 5 tokens / reorders"}
     finally:
         os.environ.pop("VACNIC_DECODE_PER_OP", None)
-        with torch.no_grad():
-            for (p_, _), sv in zip(scaled, saved):
-                p_.data.copy_(sv)
-            model.arena.refresh_shadow()
         model.__dict__.pop("_decode_sessions", None)
     return out
 
@@ -360,8 +337,7 @@ def decode_leg(model, cfg, n=6):
     t = sum(times) / len(times)
     res = {"metric": "captions/sec, batch 1, beam 5, max_length 50, length_penalty 2.0 (BASELINE configs[4])", "value": round(1.0 / t, 2),
            "unit": "captions/s", "ms_per_caption": round(t * 1e3, 1), "tokens": tokens, "n": len(times), "includes": "ViT + encoder + beam search"}
-    res.update({k: check[k] for k in ("ids_match_per_op", "ids_match_planted", "planted_margin_min", "default_path") if k in check})
-    res["id_check"] = check.get("note") or check.get("error")
+    res["id_check"] = check
     return res
 
 
@@ -611,8 +587,9 @@ def main():
                         break
                 except Exception:
                     continue
-            # algorithmic bytes of the same launches: X[M,K] + W[N,K] read once, out[M,N] written once, bf16
-            alg = sum(2.0 * (m_ * k_ + n_ * k_ + m_ * n_) for kd, _, _, _, (m_, n_, k_) in timer.rec if kd == kind and n_ > 0) / max(n, 1)
+            # algorithmic bytes of the same launches: X[M,K] and W[N,K] read once, out[M,N] written once (read + written when it
+            # accumulates), plus one [M,N] bf16 pass per epilogue operand (saved pre-activation, residual, activation-backward source)
+            alg = sum(r_[5] for r_ in timer.rec if r_[0] == kind) / max(n, 1)
             roof = {"bound": "mfma", "kernel": names[kind], "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                     "traffic_note": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
