@@ -71,6 +71,32 @@ def _worker(rank, world, port, q):
         err = (m.arena.grad - both).abs().max().item()
         assert err <= 2.0 ** -7 * both.abs().max().item() and err > 0.0, err
         assert not w16.works and not w16.launched
+        # reduce_and_step: the optimizer is driven bucket by bucket, each range only after ITS all-reduce has finished, every
+        # element exactly once, schedule first
+        class FakeOpt:
+            def __init__(self):
+                self.calls, self.seen = [], torch.zeros(m.arena.n, dtype=torch.bool)
+
+            def begin_step(self):
+                self.calls.append("begin")
+
+            def step_range(self, a, b):
+                assert self.calls and self.calls[0] == "begin"
+                assert torch.allclose(m.arena.grad[a:b], torch.full((b - a,), 3.0)), "range stepped before its bucket was reduced"
+                assert not self.seen[a:b].any()
+                self.seen[a:b] = True
+                self.calls.append((a, b))
+
+            def step(self, clip_norm=None):
+                self.calls.append(("full", clip_norm))
+        m.arena.grad.fill_(float(rank + 1))
+        fo = FakeOpt()
+        w.reduce_and_step(fo)
+        assert fo.seen.all() and len(fo.calls) == 1 + len(tr.buckets) and not w.works and not w.launched and not w.order
+        m.arena.grad.fill_(float(rank + 1))
+        fo = FakeOpt()
+        w.reduce_and_step(fo, clip_norm=0.1)                # clipping needs the global norm: plain reduce, one step
+        assert fo.calls == [("full", 0.1)] and torch.allclose(m.arena.grad, torch.full_like(m.arena.grad, 3.0))
         # expect() is ignored when the caller says no grad is needed (inference under no_grad)
         ddp.expect(False, params[0].grad)
         assert all(v == 0 for v in tr.pending.values())

@@ -84,6 +84,37 @@ def _worker(rank, world, port, q):
             res[transport] = {"losses": losses, "probe": gavg[::9973].double().cpu().tolist(), "norm": gavg.double().norm().item()}
             kept[transport] = gavg
             ddp.TRACKER = None
+        # the pipelined optimizer (reduce_and_step: AdamW bucket by bucket behind the all-reduces) == reduce, then one AdamW launch
+        from vacnic_amd.training import FusedAdamW, train_step
+        w = ddp.DistributedDataParallel(model, bucket_bytes=8 << 20)
+        opt = FusedAdamW(model.arena, lr=1e-3, num_warmup_steps=0, num_training_steps=10, world_size=world)
+        snap = [t.clone() for t in (model.arena.flat32, model.arena.exp_avg, model.arena.exp_avg_sq, opt.hyper)]
+        mine = _batch(cfg, rank * B, (rank + 1) * B)
+        results = []
+        for pipelined in (True, False):
+            for t, s_ in zip((model.arena.flat32, model.arena.exp_avg, model.arena.exp_avg_sq, opt.hyper), snap):
+                t.copy_(s_)
+            model.arena.refresh_shadow(); model.arena.grad.zero_()
+            if pipelined:
+                train_step(w, guide, opt, mine, args)                          # -> reduce_and_step
+            else:
+                from vacnic_amd.training import forward_losses
+                total, _, _ = forward_losses(w, guide, mine, args)
+                with torch.autograd.set_multithreading_enabled(False):
+                    total.backward()
+                streams.join_all()
+                w.reduce_gradients()
+                opt.step()
+            torch.cuda.synchronize()
+            results.append((model.arena.flat32.clone(), model.arena.flat16.float().clone(), model.arena.grad.abs().max().item()))
+        dp = ((results[0][0] - results[1][0]).norm() / (results[1][0] - snap[0]).norm()).item()
+        res["pipelined_update_rel_diff"] = dp
+        res["pipelined_grad_left"] = results[0][2]
+        res["pipelined_shadow_ok"] = bool(torch.equal(results[0][1] != 0, results[1][1] != 0))
+        ddp.TRACKER = None
+        for t, s_ in zip((model.arena.flat32, model.arena.exp_avg, model.arena.exp_avg_sq), snap):
+            t.copy_(s_)
+        model.arena.refresh_shadow(); model.arena.grad.zero_()
         # the single-process references, computed by rank 0 with the (broadcast) rank-0 weights and no reducer
         if rank == 0:
             shard = [_fwd_bwd(model, guide, _batch(cfg, s * B, (s + 1) * B), args) for s in range(world)]
@@ -126,6 +157,11 @@ def test_two_ranks_match_one_rank_per_shard_and_on_the_concatenated_batch():
         # both ranks hold the same reduced gradient (probe of every 9973rd element + norm)
         assert by_rank[0][transport]["probe"] == by_rank[1][transport]["probe"], transport   # plain lists: no tensors through the queue
         assert by_rank[0][transport]["norm"] == by_rank[1][transport]["norm"], transport
+    # AdamW pipelined bucket by bucket behind the all-reduces == one AdamW launch after the reduce (same update, gradient arena
+    # cleared, bf16 shadow refreshed everywhere), on both ranks
+    for r in (0, 1):
+        assert by_rank[r]["pipelined_update_rel_diff"] <= 1e-4, by_rank[r]["pipelined_update_rel_diff"]
+        assert by_rank[r]["pipelined_grad_left"] == 0.0 and by_rank[r]["pipelined_shadow_ok"]
     # concatenated batch on one rank: CE (equal token counts per shard) and CoLaM are sample means -> equal to the shard mean;
     # SECLA is NOT (in-batch negatives are per rank by design, TRAIN:326-330): the N-rank value is the per-shard mean
     whole = ref["whole_losses"]

@@ -63,6 +63,16 @@ class FusedAdamW:
         K.adamw(a.flat32, a.grad, a.exp_avg, a.exp_avg_sq, a.flat16, self.hyper, a.n, self.betas[0], self.betas[1],
                 self.eps, self.wd, grad_scale=1.0 / self.world, zero_grad=True, clip_coef=clip)
 
+    def begin_step(self):
+        """first half of step() for a range-wise update (DistributedDataParallel.reduce_and_step): schedule + counters once."""
+        K.lr_step(self.hyper, self.lr, self.warmup, self.total, ops.Rng.device_counter())
+
+    def step_range(self, start, end):
+        """AdamW on arena elements [start, end) (a DDP bucket whose all-reduce has finished); begin_step() comes first."""
+        a = self.arena
+        K.adamw(a.flat32[start:end], a.grad[start:end], a.exp_avg[start:end], a.exp_avg_sq[start:end], a.flat16[start:end], self.hyper,
+                end - start, self.betas[0], self.betas[1], self.eps, self.wd, grad_scale=1.0 / self.world, zero_grad=True)
+
     def zero_grad(self):
         pass            # fused into step(): the AdamW kernel clears the gradient arena it just consumed
 
@@ -264,9 +274,11 @@ def train_step(model, guide, optimizer, batch, args: TrainArgs, ready=None, towe
         # block per step — the one ATen kernel left inside the step (tools/aten_in_step.py), invisible to a launch plan
         total.backward(ops.const_one(total.device))
     streams.join_all()                       # weight-gradient side stream -> compute stream
+    clip = None if args.no_clip_norm else args.clip_norm                         # TRAIN:365-366
     if isinstance(model, DistributedDataParallel):
-        model.reduce_gradients()
-    optimizer.step(clip_norm=None if args.no_clip_norm else args.clip_norm)      # TRAIN:365-366
+        model.reduce_and_step(optimizer, clip)       # all-reduce tail overlapped with the optimizer of the finished buckets
+    else:
+        optimizer.step(clip_norm=clip)
     optimizer.zero_grad()
     return out4
 
