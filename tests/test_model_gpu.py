@@ -824,7 +824,7 @@ def test_whole_step_hipgraph_replays_like_eager():
 
 def test_attention_and_activation_dropout_on_the_operator_surface():
     """config.attention_dropout / activation_dropout > 0 (MFULL:546,649,740,874; 0.0 in the hub configs, but part of the
-    reference's surface): eval mode ignores them (same losses as the p = 0 model to the bit), training mode applies Philox masks
+    reference's surface): eval mode ignores them (same losses as the p = 0 model), training mode applies Philox masks
     that are reproducible from the seed, change with it, and are regenerated in backward (a second backward-capable step gives
     the same gradients); the whole step also trains (finite, decreasing loss) with all three dropouts on."""
     from vacnic_amd import ops, synthetic
@@ -843,7 +843,8 @@ def test_attention_and_activation_dropout_on_the_operator_surface():
     with torch.no_grad():
         l0 = forward_losses(m0, g0, batch, args)[1]
         l1 = forward_losses(m1, g1, batch, args)[1]
-    assert torch.equal(l0, l1), "eval mode: dropout probabilities have no effect"
+    # (two model instances: equal up to the arrival order of the loss kernels' atomic sums)
+    assert torch.allclose(l0, l1, rtol=1e-5, atol=0.0), ("eval mode: dropout probabilities have no effect", l0.tolist(), l1.tolist())
     m1.train()
 
     def grads(seed):
