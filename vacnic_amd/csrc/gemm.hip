@@ -435,11 +435,18 @@ extern "C" int vacnic_wgrad_group(const vacnic_wgrad_job* jobs, int64_t njobs, v
     if (env_debug < 0) { const char* e = getenv("VACNIC_GEMM_DEBUG"); env_debug = e ? atoi(e) : 0; }
     g.debug = env_debug & ~8;
   }
+  static int phase_rows = -1;            // rows of the reduction per launch (VACNIC_WGRAD_PHASE_ROWS; 0 = whole reduction in one launch)
+  if (phase_rows < 0) { const char* e = getenv("VACNIC_WGRAD_PHASE_ROWS"); phase_rows = e ? atoi(e) : 0; phase_rows = (phase_rows + BK - 1) / BK * BK; }
   auto flush = [&]() -> int {
     if (g.nunits == 0) return VACNIC_OK;
-    const int e = launch_group128(g, (hipStream_t)stream);
+    int kmax = 0;
+    for (int i = 0; i < g.nunits; ++i) kmax = g.u[i].K > kmax ? g.u[i].K : kmax;
+    g.k_per_phase = phase_rows > 0 ? phase_rows : (kmax + BK - 1) / BK * BK;
+    const int phases = (kmax + g.k_per_phase - 1) / g.k_per_phase;
+    for (g.kphase = 0; g.kphase < phases; ++g.kphase)
+      if (int e = launch_group128(g, (hipStream_t)stream)) { g.nunits = 0; return e; }
     g.nunits = 0;
-    return e;
+    return VACNIC_OK;
   };
   auto span = [](int64_t rows, int64_t cols, int64_t ld) { return ((rows - 1) * ld + cols) * 2; };
   for (int64_t j = 0; j < njobs; ++j) {

@@ -829,6 +829,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
 // re-read by its 8 consumers from that XCD's L2 — the traffic of the K-slice-per-XCD split-K mapping without its fp32
 // atomics (32 MB of memory-side atomics for a 1024 x 1024 gradient at split 8: ~25 of the launch's 60 us), and the sums are
 // bitwise reproducible: every output element has ONE writer and a fixed summation order.
+// Optionally (VACNIC_WGRAD_PHASE_ROWS) a long reduction is cut into PHASES, one launch each over the same grid (dW read-modify-
+// written once per phase): shorter-lived workgroups.  Measured, it does not change how the encoder-sized groups delay the compute
+// stream's chain (67.4 vs 67.4 ms/step at 4096 rows, 68.5 at 2048: profiles/r3_step_ab_wgrad.txt), so it is off by default; what
+// the step time wants is decided in ops._groupable (only reductions of <= 4096 rows are grouped).
 constexpr int GROUP_UT = 8;                 // tiles per unit side (128-wide tiles: 1024 x 1024 outputs per unit)
 constexpr int GROUP_MAX_UNITS = 16;
 struct GroupUnit {
@@ -837,7 +841,7 @@ struct GroupUnit {
   int um0, un0;                             // first output row / column of the unit
   unsigned x_bytes, w_bytes;
 };
-struct GroupP { GroupUnit u[GROUP_MAX_UNITS]; int nunits; int debug; };
+struct GroupP { GroupUnit u[GROUP_MAX_UNITS]; int nunits; int debug; int kphase; int k_per_phase; };   // this launch reduces rows [kphase * k_per_phase, +k_per_phase) of every unit
 
 template <int BM, int BN, int WM, int WN, int BKT, int NSTAGE, bool PIPE>
 __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_group_kernel(GroupP g) {
@@ -849,16 +853,16 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_group_kernel(GroupP g) {
   const int tm = t / GROUP_UT, tn = t % GROUP_UT;
   const GroupUnit& u = g.u[unit];
   const int m0 = u.um0 + tm * BM, n0 = u.un0 + tn * BN;
-  if (m0 >= u.M || n0 >= u.N) return;
+  if (m0 >= u.M || n0 >= u.N || g.kphase * g.k_per_phase >= u.K) return;
   GemmP p;
   p.x = u.x; p.w = u.w; p.bias = nullptr; p.out = u.out; p.preact = nullptr; p.dact_src = nullptr; p.residual = nullptr;
   p.xsum = u.xsum;
   p.M = u.M; p.N = u.N; p.K = u.K; p.ldx = u.ldx; p.ldw = u.ldw; p.ldo = u.ldo;
-  p.act = VACNIC_ACT_NONE; p.out_mode = 2; p.split_k = 1; p.k_per_split = (u.K + BK - 1) / BK * BK;
+  p.act = VACNIC_ACT_NONE; p.out_mode = 2; p.split_k = 1; p.k_per_split = g.k_per_phase;
   p.alpha = 1.0f; p.x_bytes = u.x_bytes; p.w_bytes = u.w_bytes;
   p.tiles_m = GROUP_UT; p.tiles_n = min(GROUP_UT, (u.N - u.un0 + BN - 1) / BN);
   p.ce_col0 = 0; p.debug = g.debug;
-  gemm_tile<BM, BN, WM, WN, BKT, NSTAGE, PIPE, true, true, false>(p, m0, n0, tn, 0);
+  gemm_tile<BM, BN, WM, WN, BKT, NSTAGE, PIPE, true, true, false>(p, m0, n0, tn, g.kphase);
 }
 
 template <int BM, int BN, int WM, int WN, int BKT, int NSTAGE, bool PIPE>

@@ -113,15 +113,22 @@ def stream_hop(src, dst, *xs):
 
 
 # ---- grouped weight gradients -------------------------------------------------------------------------------------------
-# A weight gradient with a long reduction (M = B*S rows) and a small output (d x d .. 4d x d) cannot fill 256 CUs without
-# split-K, and split-K sums through fp32 atomics (32 MB of them for one 1024 x 1024 gradient: ~25 of its 60 us).  Weight
-# gradients are needed only by AdamW / the DDP reducer, so they are DEFERRED: jobs queue up during backward and leave in groups
-# of WGRAD_GROUP_UNITS output blocks of 1024 x 1024, each block with its full reduction on one XCD (vacnic_wgrad_group): no
-# atomics on dW, bitwise reproducible sums, a quarter of the launches.  The queue empties at the end of backward (autograd
-# engine callback).  VACNIC_WGRAD_GROUP=0 restores one split-K GEMM per Linear.
+# A weight gradient with a long reduction (M rows) and a small output (d x d .. 4d x d) cannot fill 256 CUs without split-K,
+# and split-K sums through fp32 atomics.  Weight gradients are needed only by AdamW / the DDP reducer, so they can be DEFERRED:
+# jobs queue up during backward and leave in groups of WGRAD_GROUP_UNITS output blocks of 1024 x 1024, each block with its full
+# reduction on one XCD (vacnic_wgrad_group): no atomics on dW, bitwise reproducible sums, a fraction of the launches.  The queue
+# empties at the end of backward (autograd engine callback).
+# WHICH jobs are grouped is decided by the whole step, not by the kernel alone (same-box A/B, profiles/r3_step_ab_wgrad.txt):
+#   grouped everything 67.4 ms/step | split-K everything (round 2) 66.6 | grouped for M <= 4096, split-K above: 65.8
+# Alone, the grouped kernel wins on every shape (d x d at M = 16384: 68 -> 41 us), but the weight gradients share the GPU with the
+# compute stream's dgrad chain, and the encoder-sized groups (16 blocks x 16384 rows: 0.6 ms of every CU) delay that chain by
+# more than they save; the decoder-sized jobs (M = B*T = 2048: 1.8-3.9x faster grouped, 72 launches -> 12) are the clear win.
+# VACNIC_WGRAD_GROUP=0: one split-K GEMM per Linear.  VACNIC_WGRAD_GROUP_MAX_M=<rows>: group up to that reduction length
+# (a very large value = every weight gradient grouped: the deterministic mode).
 WGRAD_GROUP = __import__("os").environ.get("VACNIC_WGRAD_GROUP", "1") != "0"
-WGRAD_GROUP_UNITS = 16
+WGRAD_GROUP_UNITS = int(__import__("os").environ.get("VACNIC_WGRAD_GROUP_UNITS", "16"))     # queued output blocks that trigger a launch
 WGRAD_GROUP_MIN_M = 1024
+WGRAD_GROUP_MAX_M = int(__import__("os").environ.get("VACNIC_WGRAD_GROUP_MAX_M", "4096"))
 
 
 class _WgradQueue:
@@ -192,7 +199,7 @@ def flush_wgrads():
 
 
 def _groupable(dy2d, x2d, spec, M):
-    return (WGRAD_GROUP and spec.wgrad is not None and not _NO_XSUM and M >= WGRAD_GROUP_MIN_M and spec.N >= 512 and spec.K >= 512
+    return (WGRAD_GROUP and spec.wgrad is not None and not _NO_XSUM and WGRAD_GROUP_MIN_M <= M <= WGRAD_GROUP_MAX_M and spec.N >= 512 and spec.K >= 512
             and dy2d.stride(0) % 8 == 0 and x2d.stride(0) % 8 == 0 and spec.wgrad.stride(0) % 4 == 0
             and dy2d.shape[1] == spec.N and x2d.shape[1] == spec.K)
 
