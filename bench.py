@@ -447,6 +447,8 @@ def main():
     single_dev = os.environ.get("VACNIC_SINGLE_DEVICE") == "1"
     backend = os.environ.get("VACNIC_DIST_BACKEND", "nccl")
     torch.cuda.set_device(0 if single_dev else local)
+    if os.environ.get("VACNIC_MAIN_PRIORITY") is not None:      # A/B aid: the compute stream as a HIP stream of that priority
+        torch.cuda.set_stream(torch.cuda.Stream(priority=int(os.environ["VACNIC_MAIN_PRIORITY"])))
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     from vacnic_amd import synthetic

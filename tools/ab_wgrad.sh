@@ -14,6 +14,24 @@ PY
   tail -1 gpurun_out/_ab_line.txt | tee -a $out
 }
 rm -f gpurun_out/_ab_line.txt
+if [ "$2" = "split" ]; then
+for rep in 1 2; do
+  run "hybrid (default)" VACNIC_WGRAD_GROUP=1
+  run "hybrid, split-K factors x2" VACNIC_WGRAD_SPLIT_SCALE=2
+  run "hybrid, split-K factors x0.5" VACNIC_WGRAD_SPLIT_SCALE=0.5
+  run "hybrid, no measured tile table" VACNIC_GEMM_TUNED=0
+done
+exit 0
+fi
+if [ "$2" = "prio" ]; then
+python -c "import torch; print('priority range', torch.cuda.Stream.priority_range())" | tee -a $out
+for rep in 1 2; do
+  run "default priorities" VACNIC_WGRAD_GROUP=1
+  run "compute stream = a priority-0 side stream" VACNIC_MAIN_PRIORITY=0
+  run "compute stream priority -1 (high)" VACNIC_MAIN_PRIORITY=-1
+done
+exit 0
+fi
 if [ "$2" = "units" ]; then
 for rep in 1 2; do
   run "hybrid, flush at 16 blocks (default)" VACNIC_WGRAD_GROUP=1

@@ -122,7 +122,7 @@ def gemm(x, w, M, N, K, *, bias=None, out=None, ldx=None, ldw=None, ldo=None, x_
         if t is not None:
             tile_hint = t[0] or -1
             if out_mode == 2:
-                split_k = t[1]
+                split_k = t[1] if _SPLIT_SCALE == 1.0 else max(1, min(32, int(t[1] * _SPLIT_SCALE)))
     if tile_hint < 0:
         tile_hint = 0
     call_struct("vacnic_gemm_bf16", stream=_stream(), x=_p(x), w=_p(w), bias=_p(bias), out=_p(out), preact=_p(preact),
@@ -142,11 +142,18 @@ def gemv_ln(x, residual, gamma, beta, w, M, N, Kd, *, bias=None, out=None, ln_ou
     return out
 
 
+_SPLIT_SCALE = float(__import__("os").environ.get("VACNIC_WGRAD_SPLIT_SCALE", "1"))     # A/B aid: finer / coarser K slices in the step
+
+
 def wgrad_split(M_red, n_tiles):
     """split-K factor for a weight gradient whose reduction runs over M_red rows: aim at >= 512 workgroups."""
     s = 1
     while n_tiles * s < 512 and M_red // (s * 2) >= 512 and s < 16:
         s *= 2
+    if _SPLIT_SCALE != 1.0:
+        s = max(1, min(32, int(s * _SPLIT_SCALE)))
+        while s > 1 and M_red // s < 256:
+            s //= 2
     return s
 
 

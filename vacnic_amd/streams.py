@@ -26,11 +26,14 @@ _K._KEEP = _state["keep"]
 def enable(flag=True):
     _state["enabled"] = bool(flag) and torch.cuda.is_available()
     if _state["enabled"] and _state["wgrad"] is None:
-        _state["wgrad"] = torch.cuda.Stream()
+        # VACNIC_SIDE_PRIORITY=<int>: HIP priority of the side streams (A/B aid; default = torch's default priority)
+        prio = os.environ.get("VACNIC_SIDE_PRIORITY")
+        mk = (lambda: torch.cuda.Stream(priority=int(prio))) if prio is not None else torch.cuda.Stream
+        _state["wgrad"] = mk()
         _state["wgrad_raw"] = _state["wgrad"].cuda_stream
-        _state["aux"] = torch.cuda.Stream()
-        _state["vit"] = torch.cuda.Stream()
-        _state["branch"] = torch.cuda.Stream()
+        _state["aux"] = mk()
+        _state["vit"] = mk()
+        _state["branch"] = mk()
 
 
 def explicit():
