@@ -893,12 +893,12 @@ def test_planned_step_replays_like_eager(side_streams):
                 # "tower_graphs": the frozen towers stay hipGraph replays launched by the host, the plan is split at two marks
                 towers = FrozenTowerGraphs(model, guide, batches[0]) if side_streams == "tower_graphs" else None
                 step = PlannedTrainStep(model, guide, opt, args, batches[0], warmup=2, towers=towers)   # 2 eager steps + the recorded (executed) one
-                assert step.commands > 100 and len(step.marks) == (2 if towers is not None else 0)
+                assert step.commands > 100 and len(step.marks) == (3 if towers is not None else 0)
                 losses = []
                 for b in batches[1:] + batches[:1]:
                     c0 = _lib.CALLS
                     losses.append(step(b).tolist())
-                    assert _lib.CALLS - c0 == (5 if towers is not None else 1), "a replayed step is one C-ABI call per plan segment (+ the guide's two id kernels)"
+                    assert _lib.CALLS - c0 == (6 if towers is not None else 1), "a replayed step is one C-ABI call per plan segment (+ the guide's two id kernels)"
                 step.close()
             else:
                 for _ in range(3):

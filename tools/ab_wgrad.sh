@@ -5,7 +5,8 @@ out=gpurun_out/$tag.txt
 : > $out
 run() {
   label=$1; shift
-  env "$@" python bench.py --steps 16 --warmup 3 --no-cpu-baseline --no-extras > gpurun_out/_ab.json 2>/dev/null
+  extra=""; for kv in "$@"; do case $kv in VACNIC_BENCH_ARGS=*) extra=${kv#VACNIC_BENCH_ARGS=};; esac; done
+  env "$@" python bench.py --steps 16 --warmup 3 --no-cpu-baseline --no-extras $extra > gpurun_out/_ab.json 2>/dev/null
   python - "$label" <<'PY' >> gpurun_out/_ab_line.txt
 import json, sys
 r = json.load(open("gpurun_out/_ab.json"))
@@ -27,8 +28,9 @@ if [ "$2" = "prio" ]; then
 python -c "import torch; print('priority range', torch.cuda.Stream.priority_range())" | tee -a $out
 for rep in 1 2; do
   run "default priorities" VACNIC_WGRAD_GROUP=1
-  run "compute stream = a priority-0 side stream" VACNIC_MAIN_PRIORITY=0
-  run "compute stream priority -1 (high)" VACNIC_MAIN_PRIORITY=-1
+  run "both towers on one stream" VACNIC_ONE_TOWER_STREAM=1
+  run "one tower stream, guide after backward" VACNIC_ONE_TOWER_STREAM=1 VACNIC_GUIDE_LATE=1
+  run "two tower streams, guide after backward" VACNIC_GUIDE_LATE=1
 done
 exit 0
 fi

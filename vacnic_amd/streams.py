@@ -32,7 +32,11 @@ def enable(flag=True):
         _state["wgrad"] = mk()
         _state["wgrad_raw"] = _state["wgrad"].cuda_stream
         _state["aux"] = mk()
-        _state["vit"] = mk()
+        # the two frozen towers share ONE stream (ViT first: the student needs it first): same-box A/B 65.1 vs 66.0 ms/step
+        # (profiles/r3_step_ab_towers.txt) — two towers running beside each other AND beside the backward chain take more CUs away
+        # from that chain than their overlap buys.  VACNIC_TWO_TOWER_STREAMS=1: one stream each (rounds 1-2).
+        # (the torch-context schedule of VACNIC_EXPLICIT_STREAMS=0 enqueues the guide before the ViT: it keeps two streams)
+        _state["vit"] = mk() if (os.environ.get("VACNIC_TWO_TOWER_STREAMS") == "1" or not _state["explicit"]) else _state["aux"]
         _state["branch"] = mk()
 
 
@@ -104,7 +108,8 @@ def join_all():
     if _state["enabled"] and _state["explicit"]:
         cur = _K._stream()
         for name in ("wgrad", "aux", "vit", "branch"):
-            _K.fence(_state[name].cuda_stream, cur)
+            if name != "vit" or _state["vit"] is not _state["aux"]:
+                _K.fence(_state[name].cuda_stream, cur)
         _state["keep"].clear()
         return
     if _state["enabled"]:

@@ -178,7 +178,7 @@ def forward_losses(model, guide, batch, args: TrainArgs, ready=None, towers=None
         # frozen towers as two hipGraph replays on their side streams (FrozenTowerGraphs)
         src_mask, tgt_mask, tgt_in, ev_prep = towers.launch(batch, ready)
         main.wait_event(ev_prep)
-        main.wait_stream(vis)
+        main.wait_event(towers.ev_vit)
         img_cls, gh = towers.img_cls, towers.gh
         for tns in (src_mask, tgt_mask, tgt_in):
             tns.record_stream(main)
@@ -199,10 +199,10 @@ def forward_losses(model, guide, batch, args: TrainArgs, ready=None, towers=None
         K.fence(aux_raw, main_raw)              # the student needs the masks now, the guide's output only at the CoLaM loss
         with K.launch_on(vis_raw):              # the student's encoder input needs the image feature: ViT goes first
             img_cls = extract_clip_img_feat(net.clip_model, batch["img_tensor"])[feat]
+        K.fence(vis_raw, main_raw)              # (before the guide is enqueued: the towers may share one stream)
         if guide is not None:
             with K.launch_on(aux_raw):
                 gh = guide(input_ids=src, attention_mask=src_mask, decoder_input_ids=tgt_in)["decoder_hidden_states"][-1]   # TRAIN:293-294
-        K.fence(vis_raw, main_raw)
     else:
         # id preprocessing + frozen guide forward on the aux stream, frozen ViT on its own stream: they depend only on
         # the batch, so they fill the bubbles of the main chain (and of the previous step's AdamW)
@@ -274,6 +274,8 @@ def train_step(model, guide, optimizer, batch, args: TrainArgs, ready=None, towe
         # block per step — the one ATen kernel left inside the step (tools/aten_in_step.py), invisible to a launch plan
         total.backward(ops.const_one(total.device))
     streams.join_all()                       # weight-gradient side stream -> compute stream
+    if _PLAN is not None and _PLAN.towers is not None:
+        _PLAN.mark("backward_done")          # (the host can start the next step's guide graph behind this point)
     clip = None if args.no_clip_norm else args.clip_norm                         # TRAIN:365-366
     if isinstance(model, DistributedDataParallel):
         model.reduce_and_step(optimizer, clip)       # all-reduce tail overlapped with the optimizer of the finished buckets
@@ -405,6 +407,7 @@ class PlannedTrainStep:
         if streams.enabled() and not streams.explicit():
             raise RuntimeError("PlannedTrainStep needs explicit scheduling (VACNIC_EXPLICIT_STREAMS=0 is set)")
         self.towers = towers
+        self.ev_bwd = None
         self.static = {k: v.clone() for k, v in example_batch.items()}
         for _ in range(warmup):                              # eager: lazy buffers, kernel loading, allocator warm-up
             train_step(model, guide, optimizer, self.static, args, None, towers)
@@ -434,14 +437,18 @@ class PlannedTrainStep:
 
     def _before(self, batch=None, ready=None):
         if self.towers is not None:
-            self.towers.launch_graphs(batch if batch is not None else self.static, ready)
-            torch.cuda.current_stream().wait_stream(streams.vit_stream())      # the student's encoder needs the image feature
+            late = self.ev_bwd if __import__("os").environ.get("VACNIC_GUIDE_LATE", "0") == "1" else None
+            self.towers.launch_graphs(batch if batch is not None else self.static, ready, guide_after=late)
+            torch.cuda.current_stream().wait_event(self.towers.ev_vit)         # the student's encoder needs the image feature
 
     def _at(self, what):
         if what == "join_guide":
             torch.cuda.current_stream().wait_stream(streams.aux_stream())
         elif what == "towers_consumed":
             self.towers.mark_consumed()
+        elif what == "backward_done":
+            self.ev_bwd = torch.cuda.Event()
+            self.ev_bwd.record()
 
     def __call__(self, batch, ready=None):
         """ready: optional event after which `batch` is resident in HBM (the tower graphs then start on it instead of behind the
@@ -493,6 +500,7 @@ class FrozenTowerGraphs:
         self.mask_s, _ = K.prep_ids(self.src_s, self.pad)
         _, self.tgtin_s = K.prep_ids(example_batch["caption_ids"].clone(), self.pad, start_id=self.start)
         self.consumed = None
+        self.ev_vit = None
         self.gh = self.g_guide = None
 
         def guide_body():
@@ -538,6 +546,8 @@ class FrozenTowerGraphs:
         with torch.cuda.stream(vis):                 # the student's encoder input needs the image feature: ViT goes first
             self.img_s.copy_(batch["img_tensor"], non_blocking=True)
             self.g_vit.replay()
+            self.ev_vit = torch.cuda.Event()
+            self.ev_vit.record(vis)                  # (the towers may share one stream: wait for THIS, not for the stream's tail)
         if self.g_guide is not None:
             with torch.cuda.stream(aux):             # the guide's output is needed only by the CoLaM loss
                 self.src_s.copy_(src, non_blocking=True)
@@ -549,7 +559,7 @@ class FrozenTowerGraphs:
         batch["img_tensor"].record_stream(vis)
         return src_mask, tgt_mask, tgt_in, ev_prep
 
-    def launch_graphs(self, batch, ready=None):
+    def launch_graphs(self, batch, ready=None, guide_after=None):
         """both tower replays only (a launch plan computes the id masks itself): the guide's id inputs are derived here on its own
         stream from the batch."""
         aux, vis = streams.aux_stream(), streams.vit_stream()
@@ -566,8 +576,12 @@ class FrozenTowerGraphs:
         with torch.cuda.stream(vis):
             self.img_s.copy_(batch["img_tensor"], non_blocking=True)
             self.g_vit.replay()
+            self.ev_vit = torch.cuda.Event()
+            self.ev_vit.record(vis)
         if self.g_guide is not None:
             with torch.cuda.stream(aux):
+                if guide_after is not None:
+                    aux.wait_event(guide_after)      # the guide (needed only at the CoLaM loss) runs beside the previous AdamW, not its backward
                 self.src_s.copy_(batch["article_ids"], non_blocking=True)
                 K.prep_ids_into(self.src_s, self.mask_s, None, self.pad)
                 K.prep_ids_into(batch["caption_ids"], None, self.tgtin_s, self.pad, self.start)
