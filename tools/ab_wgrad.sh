@@ -28,9 +28,9 @@ if [ "$2" = "prio" ]; then
 python -c "import torch; print('priority range', torch.cuda.Stream.priority_range())" | tee -a $out
 for rep in 1 2; do
   run "default priorities" VACNIC_WGRAD_GROUP=1
-  run "both towers on one stream" VACNIC_ONE_TOWER_STREAM=1
-  run "one tower stream, guide after backward" VACNIC_ONE_TOWER_STREAM=1 VACNIC_GUIDE_LATE=1
-  run "two tower streams, guide after backward" VACNIC_GUIDE_LATE=1
+  run "no branch stream (encoder branches on the compute stream)" VACNIC_NO_BRANCH_STREAM=1
+  run "no weight-gradient stream" VACNIC_NO_WGRAD_STREAM=1
+  run "two tower streams" VACNIC_TWO_TOWER_STREAMS=1
 done
 exit 0
 fi

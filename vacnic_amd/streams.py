@@ -58,8 +58,12 @@ def enabled():
     return _state["enabled"]
 
 
+_NO_WGRAD = os.environ.get("VACNIC_NO_WGRAD_STREAM") == "1"       # A/B aids: that work stays on the compute stream
+_NO_BRANCH = os.environ.get("VACNIC_NO_BRANCH_STREAM") == "1"
+
+
 def wgrad_stream():
-    return _state["wgrad"] if _state["enabled"] else None
+    return _state["wgrad"] if _state["enabled"] and not _NO_WGRAD else None
 
 
 def wgrad_raw():
@@ -88,7 +92,7 @@ def branch_stream():
     """stream of the encoder layer's small-token branches (image / face / name streams of MFULL:647-691: a dozen GEMMs over
     20-80 tokens per sample that occupy a fraction of the GPU) — they run beside the text self-attention block of the same
     layer, forward and backward (the autograd engine replays each node on the stream of its forward)."""
-    return _state["branch"] if _state["enabled"] else None
+    return _state["branch"] if _state["enabled"] and not _NO_BRANCH else None
 
 
 def side_streams():
