@@ -137,7 +137,8 @@ int vacnic_attn_fwd(const vacnic_attn_fwd_args* a, void* stream);
 
 typedef struct {
   const void* q; const void* k; const void* v; const void* out; const void* dout;
-  const float* lse; float* delta;            /* delta: f32 [B][H][Tq] scratch (rowsum(dO*O)) */
+  const float* lse; float* delta;            /* delta: f32 [B][H][Tq] scratch: sum_k P[q][k] dP[q][k], formed by a sweep of the kernels' own
+                                                P and dP for Tq <= 128 and as rowsum(dO*O) above (VACNIC_ATTN_DELTA=1 / 2 force one form) */
   void* dq; void* dk; void* dv;              /* bf16, same layouts/strides as q,k,v */
   const uint8_t* key_mask;
   int64_t B, H, Tq, Tk;

@@ -612,8 +612,11 @@ def test_cfg2_full_depth_matches_oracle_losses_states_and_gradients():
     """BASELINE configs[1] at FULL depth and width — BART-large 12+12 layers, d=1024, CLIP ViT-L/14 (24 layers), full VACNIC
     (clipcap prompt, SECLA, CoLaM a=0.5 m=1.0), 512-token articles, 64-token captions, dropout 0 — at batch 2, where the CPU
     oracle's forward + backward takes seconds: bf16 through 24 residual layers against the fp32 restatement (SURVEY §7 hard
-    part (b)).  All four loss terms <= 1e-2 relative, the face / decoder states <= 2e-2 relative L2, and the gradients of a
-    dozen parameters spread over the depth of both stacks <= 5e-2 relative L2."""
+    part (b)).  All four loss terms <= 1e-2 relative, the face / decoder states <= 2e-2 relative L2, and the gradients of 19
+    parameters spread over the depth of both stacks <= 4.5e-2 relative L2 (round 2: 5e-2 with the worst at 4.7e-2 — the q / k
+    projection gradients of the decoder, whose dS = P o (dP - delta) subtracts nearly equal numbers: delta now comes from the
+    attention kernels' own P and dP instead of rowsum(dO o O_bf16), worst of those 3.2e-2; what remains on top is the face
+    stream at 3.9e-2, where SECLA's arg-max routing picks between near-tied bf16 similarities)."""
     from oracle import vacnic_oracle as O
     from vacnic_amd import streams, synthetic
     from vacnic_amd.config import bart_large_vit_l14
@@ -658,9 +661,11 @@ def test_cfg2_full_depth_matches_oracle_losses_states_and_gradients():
         assert og is not None and og.abs().max() > 0, n
         r = rel(params[n].grad, og)
         worst.append((r, n))
-        assert r <= 5e-2, f"grad {n}: rel L2 err {r:.3g}"
+        assert r <= 4.5e-2, f"grad {n}: rel L2 err {r:.3g}"
     worst.sort(reverse=True)
     print("cfg2 full depth: losses", out4.tolist(), "worst grads", worst[:4])
+    attn = [r for r, n in worst if "q_proj" in n or "k_proj" in n]
+    assert max(attn) <= 3.6e-2, ("attention projection gradients (consistent delta)", attn)
 
 
 def test_cfg2_full_size_step_properties():

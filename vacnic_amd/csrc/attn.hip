@@ -79,7 +79,7 @@ __device__ __forceinline__ void lds_barrier() {
 
 struct AttnP {
   const bf16_t* q; const bf16_t* k; const bf16_t* v; bf16_t* out; float* lse;
-  const bf16_t* dout; const float* delta; bf16_t* dq; bf16_t* dk; bf16_t* dv;
+  const bf16_t* dout; const float* delta; float* delta_out; bf16_t* dq; bf16_t* dk; bf16_t* dv;
   const uint8_t* key_mask;
   int B, H, Tq, Tk;
   int ldq, ldk, ldv, ldo, lddq, lddk, lddv;
@@ -473,7 +473,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnP p) {
 // dQ: wave owns 32 queries (on the lane); sweeps 64-key tiles of K and V.
 //   S^T[k][q]  = K Q^T ; dP^T[k][q] = V dO^T ; dQ^T[d][q] += K^T dS^T (A = K^T via tr-read)
 // =================================================================================================
-template <bool DROP>
+// DELTA_PASS: the same sweep without the dQ product — it only forms delta[q] = sum_k P[q][k] dP[q][k] (with the dropout mask) and
+// writes it for the two kernels proper.  delta = rowsum(dO o O) is the same number analytically, but O was rounded to bf16 on its way
+// out of the forward and dS = P o (dP - delta) subtracts two nearly equal quantities whenever the value rows share a large common
+// component (they do: hidden states of one sequence are 80-99 % parallel): measured on such inputs, dQ is off by 1.1 % with
+// rowsum(dO o O_bf16) and by 0.17 % with a delta formed from the same P and dP the kernels use (tools/attn_bwd_error.py;
+// full-depth q_proj / k_proj weight gradients 4.7e-2 / 3.5e-2 -> see tests).
+template <bool DROP, bool DELTA_PASS>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -511,8 +517,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
   float lse_q = INFINITY, delta_q = 0.f;
   if (qidx < p.Tq) {
     lse_q = p.lse[((long)b * p.H + hd) * p.Tq + qidx];
-    delta_q = p.delta[((long)b * p.H + hd) * p.Tq + qidx];
+    if (!DELTA_PASS) delta_q = p.delta[((long)b * p.H + hd) * p.Tq + qidx];
   }
+  float dsum = 0.f;
   f32x16 dq[2];
   dq[0] = (f32x16)(0.f); dq[1] = (f32x16)(0.f);
   DropCtx dctx;
@@ -550,18 +557,27 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
           float v = s[4 * g + e] * p.scale + bias[e];
           if (p.causal && (kbase + e) > qidx) v += FMIN;
           const float pe = __expf(v - lse_q);
-          dp[4 * g + e] = pe * ((DROP ? dp[4 * g + e] * mk[e] : dp[4 * g + e]) - delta_q) * p.scale;
+          const float dpm = DROP ? dp[4 * g + e] * mk[e] : dp[4 * g + e];
+          if (DELTA_PASS) dsum += pe * dpm;                     // (pe is exactly 0 for padding keys: bias = -inf)
+          else dp[4 * g + e] = pe * (dpm - delta_q) * p.scale;
         }
       }
+      if (!DELTA_PASS) {
 #pragma unroll
-      for (int ss = 0; ss < 2; ++ss) {
-        const bf16x8 dsf = pack_acc(dp, ss);
+        for (int ss = 0; ss < 2; ++ss) {
+          const bf16x8 dsf = pack_acc(dp, ss);
 #pragma unroll
-        for (int hb = 0; hb < 2; ++hb)
-          dq[hb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt, kb2 * 32 + 16 * ss, hb * 32, lane), dsf, dq[hb], 0, 0, 0);
+          for (int hb = 0; hb < 2; ++hb)
+            dq[hb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt, kb2 * 32 + 16 * ss, hb * 32, lane), dsf, dq[hb], 0, 0, 0);
+        }
       }
     }
     lds_barrier();
+  }
+  if (DELTA_PASS) {
+    dsum += __shfl_xor(dsum, 32, 64);                         // the two lane halves hold different keys of the same query
+    if (qidx < p.Tq && hh == 0) p.delta_out[((long)b * p.H + hd) * p.Tq + qidx] = dsum;
+    return;
   }
   if (qidx < p.Tq) {
     bf16_t* drow = p.dq + (long)b * p.bsdq + (long)qidx * p.lddq + hd * 64;
@@ -788,16 +804,29 @@ extern "C" int vacnic_attn_bwd(const vacnic_attn_bwd_args* a, void* stream) {
   if (int e = set_dropout(p, a->p_drop, a->seed, a->seed_dev, "attn_bwd")) return e;
   hipStream_t s = (hipStream_t)stream;
   const long rows = (long)p.B * p.Tq;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const bf16_t*)a->out,
-                     (const bf16_t*)a->dout, a->delta, p.B, p.H, p.Tq, p.ldo, (long)p.bso);
-  VLAUNCH_CHECK();
   const int Tk_pad = (p.Tk + 63) & ~63;
   const dim3 gkv((unsigned)(((p.Tk + 127) / 128) * p.H * p.B)), gq((unsigned)(((p.Tq + 127) / 128) * p.H * p.B));
+  const size_t lds_q = 4 * TILE_B + Tk_pad * 4;
+  p.delta_out = a->delta;
+  // delta: from the kernels' own P and dP (a sweep of the dQ kernel without its last product) for the decoder-sized problems,
+  // where it costs microseconds; rowsum(dO o O) for the long encoder sequences (a_delta_mode: 0 = by size, 1 = always the sweep,
+  // 2 = always rowsum(dO o O))
+  static int env_mode = -1;
+  if (env_mode < 0) { const char* e = getenv("VACNIC_ATTN_DELTA"); env_mode = e ? atoi(e) : 0; }
+  const bool sweep = env_mode == 1 || (env_mode == 0 && p.Tq <= 128);
+  if (sweep) {
+    if (p.drop_thr) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, true>), gq, dim3(256), lds_q, s, p);
+    else hipLaunchKernelGGL((attn_bwd_dq_kernel<false, true>), gq, dim3(256), lds_q, s, p);
+  } else {
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const bf16_t*)a->out,
+                       (const bf16_t*)a->dout, a->delta, p.B, p.H, p.Tq, p.ldo, (long)p.bso);
+  }
+  VLAUNCH_CHECK();
   if (p.drop_thr) hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, gkv, dim3(256), 4 * TILE_B + 2 * 128 * 4, s, p);
   else hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, gkv, dim3(256), 4 * TILE_B + 2 * 128 * 4, s, p);
   VLAUNCH_CHECK();
-  if (p.drop_thr) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, gq, dim3(256), 4 * TILE_B + Tk_pad * 4, s, p);
-  else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, gq, dim3(256), 4 * TILE_B + Tk_pad * 4, s, p);
+  if (p.drop_thr) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, false>), gq, dim3(256), lds_q, s, p);
+  else hipLaunchKernelGGL((attn_bwd_dq_kernel<false, false>), gq, dim3(256), lds_q, s, p);
   VLAUNCH_CHECK();
   return VACNIC_OK;
 }
