@@ -919,6 +919,37 @@ def test_planned_step_replays_like_eager(side_streams):
         streams.enable(False)
 
 
+def test_planned_step_draws_fresh_dropout_masks_every_replay():
+    """the host-side dropout seeds are frozen into a recorded plan; the per-step counter they are mixed with lives in device memory
+    (advanced by vacnic_lr_step inside the plan), so every replay draws new masks — hidden, attention-probability and activation
+    dropout all on: replaying the SAME batch twice gives different (finite) losses, and the forward of an untouched copy of the
+    weights is reproduced when the counter is put back."""
+    from vacnic_amd import ops, streams, synthetic
+    from vacnic_amd.config import ClipVisionConfig
+    from vacnic_amd.training import FusedAdamW, PlannedTrainStep, TrainArgs, build_models, to_device
+    cfg = small_cfg(dropout=0.1, attention_dropout=0.1, activation_dropout=0.1, encoder_layers=1, decoder_layers=1)
+    vcfg = ClipVisionConfig(width=768, layers=1, patch_size=16, image_size=32, output_dim=64)
+    args = TrainArgs(num_training_steps=20, lr_bart=0.0)          # lr 0: the weights stay put, only the masks can change the losses
+    b = to_device(synthetic.make_batch(cfg, 3, S=32, T=12, F=3, seed=40, image_size=32), "cuda")
+    streams.enable(True)
+    try:
+        ops.Rng.manual_seed(3); ops.Rng.device_counter().zero_()
+        model, guide, _ = build_models(cfg, vcfg, init="synthetic", seed=0)
+        opt = FusedAdamW(model.arena, lr=0.0, weight_decay=0.0, num_warmup_steps=0, num_training_steps=20)
+        step = PlannedTrainStep(model, guide, opt, args, b, warmup=1)
+        c0 = ops.Rng.device_counter().clone()
+        l1 = step(b).clone(); l2 = step(b).clone()
+        assert torch.isfinite(l1).all() and torch.isfinite(l2).all()
+        assert not torch.equal(l1[1], l2[1]), "a replay must not reuse the previous step's dropout masks"
+        assert int(ops.Rng.device_counter().item()) == int(c0.item()) + 2
+        ops.Rng.device_counter().copy_(c0)                             # same counter, same weights (lr 0) -> same masks -> same losses
+        l3 = step(b).clone()
+        assert torch.allclose(l3, l1, rtol=1e-5), (l3.tolist(), l1.tolist())
+        step.close()
+    finally:
+        streams.enable(False)
+
+
 @pytest.mark.parametrize("variant", ["slots", "barrier"])
 @pytest.mark.parametrize("case", ["bart_base_shape", "bart_large_shape"])
 def test_decoder_step_kernel_matches_per_op_path(case, variant, monkeypatch):
