@@ -3,7 +3,10 @@
 The reference pickles the whole module object each epoch (`torch.save(model, ...)`, TRAIN:464-472) and keeps no optimizer,
 scheduler or RNG state, so a run can be evaluated but not resumed.  Here a checkpoint is a plain dict of tensors keyed by
 the REFERENCE's parameter names (the modules mirror `src/models`, so `state_dict()` of a reference model built from the
-same config loads it and vice versa), plus what a bit-for-bit continuation needs:
+same config loads it and vice versa), plus everything the continuation of a run depends on — weights, AdamW moments, schedule position and
+the dropout RNG are restored EXACTLY (the first step after a resume reproduces the uninterrupted run to fp32 round-off, 2e-5); later steps
+agree to ~1e-3 because a step itself is not run-to-run deterministic: the split-K weight gradients, the LayerNorm parameter gradients and the
+embedding scatter sum through fp32 atomics whose order varies (VACNIC_WGRAD_GROUP_MAX_M=1000000 removes the first source):
   model      {reference parameter name: fp32 tensor}   (the fp32 master copies; the bf16 shadow is derived)
   optimizer  {"exp_avg": {name: tensor}, "exp_avg_sq": {name: tensor}, "lr": float, "step": int}   — torch.optim.AdamW layout
   schedule   {"base_lr", "num_warmup_steps", "num_training_steps"}
