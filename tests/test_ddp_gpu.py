@@ -84,17 +84,44 @@ def _worker(rank, world, port, q):
             res[transport] = {"losses": losses, "probe": gavg[::9973].double().cpu().tolist(), "norm": gavg.double().norm().item()}
             kept[transport] = gavg
             ddp.TRACKER = None
-        # the pipelined optimizer (reduce_and_step: AdamW bucket by bucket behind the all-reduces) == reduce, then one AdamW launch
+        # the pipelined optimizer (reduce_and_step: AdamW bucket by bucket behind the all-reduces) == reduce, then one AdamW launch.
+        # (i) on INJECTED gradients (a different one per rank) the two must agree bit for bit — the all-reduce and AdamW are both
+        # order-independent per element; (ii) through the whole train_step against forward/backward + reduce + step.  (ii) compares
+        # two separate passes, and a pass is not bitwise reproducible when two processes share the card: the LM-head dgrad sums its
+        # vocabulary chunks with split-K fp32 atomics, whose order then varies, and about every second pass ONE bf16 element of
+        # dH rounds the other way (tools/grad_determinism.py --ddp --trace: first differing call = that GEMM).  Backward amplifies
+        # it to ~1e-5..1e-3 relative on every gradient, and AdamW's FIRST step is sign(g) lr: each of the few thousand elements
+        # whose gradient is that close to zero moves by 2 lr (measured: 0 or 1.4-1.9e-2 of the update's norm, run by run); a
+        # bucket updated with un-reduced gradients would be >= 0.2.  So (ii) is gated at 5e-2 and the exact statement is (i).
         from vacnic_amd.training import FusedAdamW, train_step
         w = ddp.DistributedDataParallel(model, bucket_bytes=8 << 20)
         opt = FusedAdamW(model.arena, lr=1e-3, num_warmup_steps=0, num_training_steps=10, world_size=world)
         snap = [t.clone() for t in (model.arena.flat32, model.arena.exp_avg, model.arena.exp_avg_sq, opt.hyper)]
         mine = _batch(cfg, rank * B, (rank + 1) * B)
-        results = []
-        for pipelined in (True, False):
-            for t, s_ in zip((model.arena.flat32, model.arena.exp_avg, model.arena.exp_avg_sq, opt.hyper), snap):
+        state = (model.arena.flat32, model.arena.exp_avg, model.arena.exp_avg_sq, opt.hyper)
+
+        def restore():
+            for t, s_ in zip(state, snap):
                 t.copy_(s_)
             model.arena.refresh_shadow(); model.arena.grad.zero_()
+
+        g_inject = kept["fp32"] * (1.0 + 0.37 * rank) + 1e-7 * rank
+        exact = []
+        for pipelined in (True, False):
+            restore()
+            model.arena.grad.copy_(g_inject)
+            if pipelined:
+                w.reduce_and_step(opt)
+            else:
+                w.reduce_gradients()
+                opt.step()
+            torch.cuda.synchronize()
+            exact.append([t.clone() for t in (model.arena.flat32, model.arena.flat16, model.arena.exp_avg, model.arena.exp_avg_sq, model.arena.grad)])
+        res["pipelined_exact"] = [bool(torch.equal(a_, b_)) for a_, b_ in zip(*exact)]
+        res["pipelined_exact_moved"] = bool((exact[0][0] != snap[0]).any().item())
+        results = []
+        for pipelined in (True, False):
+            restore()
             if pipelined:
                 train_step(w, guide, opt, mine, args)                          # -> reduce_and_step
             else:
@@ -107,8 +134,7 @@ def _worker(rank, world, port, q):
                 opt.step()
             torch.cuda.synchronize()
             results.append((model.arena.flat32.clone(), model.arena.flat16.float().clone(), model.arena.grad.abs().max().item()))
-        dp = ((results[0][0] - results[1][0]).norm() / (results[1][0] - snap[0]).norm()).item()
-        res["pipelined_update_rel_diff"] = dp
+        res["pipelined_update_rel_diff"] = ((results[0][0] - results[1][0]).norm() / (results[1][0] - snap[0]).norm()).item()
         res["pipelined_grad_left"] = results[0][2]
         res["pipelined_shadow_ok"] = bool(torch.equal(results[0][1] != 0, results[1][1] != 0))
         ddp.TRACKER = None
@@ -157,10 +183,11 @@ def test_two_ranks_match_one_rank_per_shard_and_on_the_concatenated_batch():
         # both ranks hold the same reduced gradient (probe of every 9973rd element + norm)
         assert by_rank[0][transport]["probe"] == by_rank[1][transport]["probe"], transport   # plain lists: no tensors through the queue
         assert by_rank[0][transport]["norm"] == by_rank[1][transport]["norm"], transport
-    # AdamW pipelined bucket by bucket behind the all-reduces == one AdamW launch after the reduce (same update, gradient arena
-    # cleared, bf16 shadow refreshed everywhere), on both ranks
+    # AdamW pipelined bucket by bucket behind the all-reduces == one AdamW launch after the reduce: bit for bit on injected gradients
+    # (weights, bf16 shadow, both moments, cleared gradient arena), and through train_step up to first-step sign flips (see _worker)
     for r in (0, 1):
-        assert by_rank[r]["pipelined_update_rel_diff"] <= 1e-4, by_rank[r]["pipelined_update_rel_diff"]
+        assert all(by_rank[r]["pipelined_exact"]) and by_rank[r]["pipelined_exact_moved"], by_rank[r]["pipelined_exact"]
+        assert by_rank[r]["pipelined_update_rel_diff"] <= 5e-2, by_rank[r]["pipelined_update_rel_diff"]
         assert by_rank[r]["pipelined_grad_left"] == 0.0 and by_rank[r]["pipelined_shadow_ok"]
     # concatenated batch on one rank: CE (equal token counts per shard) and CoLaM are sample means -> equal to the shard mean;
     # SECLA is NOT (in-batch negatives are per rank by design, TRAIN:326-330): the N-rank value is the per-shard mean
