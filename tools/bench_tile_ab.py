@@ -43,6 +43,13 @@ def main():
                 g()
             torch.cuda.synchronize()
             res = (out.float(), dx.float(), dw.clone(), db.clone())
+            # run-to-run: the bf16 results of 10 more launches must be bit-identical (a race in a ring / barrier scheme shows here)
+            for _ in range(10):
+                f(); d()
+                torch.cuda.synchronize()
+                if not (torch.equal(out.float(), res[0]) and torch.equal(dx.float(), res[1])):
+                    line += f"  [{h}] NOT REPRODUCIBLE"
+                    break
             if not ref:
                 ref = res
             err = [((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item() for a, b in zip(res, ref)]
