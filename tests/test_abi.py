@@ -28,6 +28,40 @@ def test_binding_covers_header(built_lib):
     assert _lib.lib.vacnic_last_error_string() is not None
 
 
+def test_ctypes_structs_match_the_header_layout(tmp_path):
+    """every argument struct of the binding has the size and the field offsets the C compiler gives the struct of the same name in
+    include/vacnic_hip.h (a field added on one side only, or in another order, would silently shift every later argument)."""
+    import shutil
+    import subprocess
+    from vacnic_amd import _lib
+    if shutil.which("gcc") is None:
+        import pytest
+        pytest.skip("no C compiler")
+    structs = {n: t for n, t in vars(_lib).items() if isinstance(t, type) and issubclass(t, ctypes.Structure) and t is not ctypes.Structure}
+    structs = {t.__name__: t for t in structs.values() if t.__name__.startswith("vacnic_")}
+    assert len(structs) >= 15, sorted(structs)
+    header = open(os.path.join(ROOT, "include", "vacnic_hip.h")).read()
+
+    def member(fname):            # the binding flattens small arrays: seq0 / seq1 <-> seq[2]
+        m = re.match(r"^(\w+?)(\d+)$", fname)
+        return f"{m.group(1)}[{m.group(2)}]" if m and re.search(rf"\b{m.group(1)}\[\d+\]", header) else fname
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "vacnic_hip.h"', "int main(void) {"]
+    for name, t in sorted(structs.items()):
+        lines.append(f'  printf("{name} %zu\\n", sizeof({name}));')
+        for fname, *_ in t._fields_:
+            lines.append(f'  printf("{name}.{fname} %zu\\n", offsetof({name}, {member(fname)}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True, capture_output=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for name, t in structs.items():
+        assert int(got[name]) == ctypes.sizeof(t), (name, got[name], ctypes.sizeof(t))
+        for fname, *_ in t._fields_:
+            assert int(got[f"{name}.{fname}"]) == getattr(t, fname).offset, (name, fname)
+
+
 def test_bad_arguments_return_status_not_abort(built_lib):
     """error convention: status code + message, never an abort (validation happens before any launch)."""
     import pytest
