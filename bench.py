@@ -613,7 +613,8 @@ def main():
                                f"launch plan replay ({planned.commands} recorded commands, 1 C-ABI call per step; K-1 steps) + 1 eager instrumented step" if planned is not None else
                                "eager multi-stream" + (", frozen towers as hipGraph replays" if towers is not None else "")),
                "host_enqueue_ms_per_step": round(host_dt / a.steps * 1e3, 2),
-               "c_abi_calls_per_step": round(calls_per_step, 1), "host_cpu_ms_per_step": round(host_cpu * 1e3, 2),
+               "c_abi_calls_per_step": round(calls_per_step, 1),
+               "host_cpu_incl_queue_backpressure_spin_ms_per_step": round(host_cpu * 1e3, 2),
                # host_enqueue / host_cpu above include the time the launching thread spins on a full HIP queue (the host runs ~2 steps
                # ahead of a GPU-bound step and is then throttled to the GPU's pace); this is the launch path's own cost: one step
                # enqueued from an idle GPU (the last warm-up step)

@@ -57,7 +57,13 @@ enum { VACNIC_ACT_NONE = 0, VACNIC_ACT_GELU = 1, VACNIC_ACT_TANH = 2, VACNIC_ACT
  *                  (fused activation backward in the dgrad of the following Linear).
  *   residual       optional bf16 [M][ldo] added after the activation.
  *   out_mode       0: bf16 store, 1: f32 store, 2: f32 atomic accumulate (out += ..; split-K ok)
- *   split_k        >=1; >1 requires out_mode 2.
+ *   split_k        >=1; >1 requires out_mode 2 or a workspace.
+ *   workspace      optional: with split_k > 1 the K slices meet through an ORDERED FIX-UP instead of fp32 atomics — every slice
+ *                  deposits its fp32 partial tile here, the last one to arrive sums them in slice order and runs the epilogue
+ *                  once — so any out_mode / activation / residual works with split_k > 1 and the result is bitwise
+ *                  reproducible.  Needs vacnic_gemm_workspace_bytes(M, N, split_k) bytes (any contents) and `counters`:
+ *                  vacnic_gemm_counters(M, N) uint32 words that are ZERO before the call (they are zero again after it).
+ *                  Launches that may run concurrently (different streams) must not share either buffer.
  * With out_mode 0 and 256-row tiles the result is rounded to bf16 once (bias and a plain activation are applied in
  * fp32 first); a saved pre-activation, the fused activation backward and the residual are then applied to that bf16
  * value — the arithmetic of a bf16 Linear followed by a bf16 elementwise op.
@@ -76,8 +82,15 @@ typedef struct {
   int32_t act, out_mode, split_k;
   float alpha;
   int32_t tile_hint;              /* 0 = library picks by problem size (M <= 8 rows: the W-streaming skinny kernel); 8 (skinny) / 64 (64x128, 4-deep ring) / 128 / 256 force a config */
+  void* workspace;                /* split-K fix-up (see above); NULL = fp32 atomics */
+  int64_t workspace_bytes;
+  uint32_t* counters;
+  int64_t counters_len;           /* words */
 } vacnic_gemm_args;
 int vacnic_gemm_bf16(const vacnic_gemm_args* a, void* stream);
+/* sizes of the split-K fix-up buffers for an M x N output (upper bounds over every tile configuration the library may pick) */
+int64_t vacnic_gemm_workspace_bytes(int64_t M, int64_t N, int64_t split_k);
+int64_t vacnic_gemm_counters(int64_t M, int64_t N);
 
 /*
  * Single-token decoder step: y = epi( LayerNorm(x + residual) . W^T + bias ), M <= 8 rows (beams x batch), K = d_model <= 1024.
@@ -128,7 +141,7 @@ typedef struct {
   int64_t ldq, ldk, ldv, ldo;
   int64_t bsq, bsk, bsv, bso;     /* batch strides in elements */
   int32_t causal; float scale;
-  /* attention-probability dropout, nn.functional.dropout(attn_weights, p=attention_dropout) of MFULL:546 (0.0 in bart-base/large):
+  /* attention-probability dropout, nn.functional.dropout(attn_weights, p=attention_dropout) of MFULL:546 (0.1 in the bart-base / bart-large hub configs):
      p_drop in [0,1) quantised to 1/256; Philox keep bits from (seed ^ f(*seed_dev), batch, head, query, key), regenerated by
      vacnic_attn_bwd from the same seed — the [B*H, Tq, Tk] mask is never stored.  lse stays the undropped log-sum-exp. */
   float p_drop; uint64_t seed; const uint64_t* seed_dev;

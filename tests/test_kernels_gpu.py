@@ -268,6 +268,38 @@ def test_gemm_wgrad_fused_bias_gradient(K, hint, M, N, K_, split):
     close(bs, 0.5 + dy[:, :M].float().sum(0), 2e-3, 2e-2 * math.sqrt(K_ / 256), f"bias gradient hint {hint} split {split}")
 
 
+@pytest.mark.parametrize("hint", [64, 128, 256, 264])
+@pytest.mark.parametrize("M,N,K_,split", [(2048, 1024, 4096, 4), (300, 520, 1000, 2), (640, 1024, 3072, 8), (257, 256, 512, 3)])
+def test_gemm_split_k_ordered_fixup(K, hint, M, N, K_, split):
+    """split_k > 1 through the ordered fix-up (workspace + arrival tickets) instead of fp32 atomics: every layout, bf16 output with
+    bias + activation + residual (impossible with atomics), fp32 store, accumulate; bitwise reproducible; counters left at zero."""
+    x = rnd(M, K_, seed=1); w = rnd(N, K_, scale=0.1, seed=2); b = rnd(N, dtype=torch.float32, seed=3); res = rnd(M, N, seed=4)
+    ref = x.float() @ w.float().t()
+    tol = 2e-2 * math.sqrt(K_ / 64)
+    kw = dict(split_k=split, fixup=True, tile_hint=hint)
+    o1 = K.gemm(x, w, M, N, K_, bias=b, act="gelu", residual=res, **kw)
+    close(o1, torch.nn.functional.gelu(ref + b) + res.float(), 1e-2, tol, f"NN bf16 + bias + gelu + residual, hint {hint} split {split}")
+    for _ in range(3):                                           # who arrives last varies; the sum order does not
+        assert torch.equal(o1, K.gemm(x, w, M, N, K_, bias=b, act="gelu", residual=res, **kw)), "fix-up must be bitwise reproducible"
+    wt = w.t().contiguous()
+    close(K.gemm(x, wt, M, N, K_, w_kstrided=True, out_mode=1, **kw), ref, 2e-3, tol, "NT f32 store")
+    # the unsplit launch sums the same products in another order: equal to fp32 round-off, and both equal the reference
+    close(K.gemm(x, wt, M, N, K_, w_kstrided=True, out_mode=1, **kw), K.gemm(x, wt, M, N, K_, w_kstrided=True, out_mode=1, tile_hint=hint), 1e-4, 1e-3, "split vs unsplit")
+    xt = torch.zeros(K_, (M + 7) // 8 * 8, device="cuda", dtype=torch.bfloat16); xt[:, :M] = x.t()
+    bs0 = torch.full((M,), 0.5, device="cuda")
+    accs = []
+    for _ in range(2):
+        acc = torch.full((M, N), 2.0, device="cuda"); bs = bs0.clone()
+        K.gemm(xt, wt, M, N, K_, out=acc, ldx=xt.shape[1], x_kstrided=True, w_kstrided=True, out_mode=2, xsum=bs, **kw)
+        accs.append(acc)
+    close(accs[0], 2.0 + ref, 2e-3, tol, "TT accumulate (weight-gradient layout)")
+    close(bs, 0.5 + x.float().sum(1), 2e-3, tol, "TT fused bias gradient beside the fix-up")
+    assert torch.equal(accs[0], accs[1]), "weight gradient through the fix-up: bitwise reproducible"
+    torch.cuda.synchronize()
+    for ws, cnt in K._FIX.values():
+        assert int(cnt.abs().sum()) == 0, "arrival counters must be zero after every launch"
+
+
 # ------------------------------------------------------------------------------------------- attention
 def attn_ref(q, k, v, key_mask, causal, scale):
     B, Tq, H, hd = q.shape

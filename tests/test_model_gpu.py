@@ -532,7 +532,7 @@ def test_cfg1_bart_base_vit_b32_only_image_full_depth_matches_oracle():
     from vacnic_amd import synthetic
     from vacnic_amd.config import bart_base_vit_b32
     from vacnic_amd.training import TrainArgs, build_models, forward_losses, to_device
-    cfg, vcfg = bart_base_vit_b32(dropout=0.0)
+    cfg, vcfg = bart_base_vit_b32(dropout=0.0, attention_dropout=0.0, activation_dropout=0.0)
     model, _, _ = build_models(cfg, vcfg, init="synthetic", seed=0)
     model.eval()
     batch = synthetic.make_batch(cfg, 2, S=512, T=64, seed=21)
@@ -571,7 +571,7 @@ def test_cfg4_long_article_1024_tokens_step_and_oracle():
         assert abs(out4[i].item() - ref[k].item()) <= 1e-2 * abs(ref[k].item()) + 1e-3, (k, out4[i].item(), ref[k].item())
     del model, guide
     torch.cuda.empty_cache()
-    cfg4, vcfg4 = bart_large_vit_l14(dropout=0.0)
+    cfg4, vcfg4 = bart_large_vit_l14(dropout=0.0, attention_dropout=0.0, activation_dropout=0.0)
     model, guide, _ = build_models(cfg4, vcfg4, init="device", seed=3)
     opt = FusedAdamW(model.arena, lr=1e-4, num_warmup_steps=0, num_training_steps=100)
     b4 = to_device(synthetic.make_batch(cfg4, 2, S=1024, T=64, seed=32, full_length=True), "cuda")
@@ -621,7 +621,7 @@ def test_cfg2_full_depth_matches_oracle_losses_states_and_gradients():
     from vacnic_amd import streams, synthetic
     from vacnic_amd.config import bart_large_vit_l14
     from vacnic_amd.training import TrainArgs, build_models, forward_losses, to_device
-    cfg, vcfg = bart_large_vit_l14(dropout=0.0)
+    cfg, vcfg = bart_large_vit_l14(dropout=0.0, attention_dropout=0.0, activation_dropout=0.0)
     streams.enable(True)
     model, guide, _ = build_models(cfg, vcfg, init="synthetic", seed=0)
     model.train()                                            # dropout is 0: train mode only keeps the autograd graph
@@ -679,7 +679,7 @@ def test_cfg2_full_size_step_properties():
     from vacnic_amd import kernels as K, streams, synthetic
     from vacnic_amd.config import bart_large_vit_l14
     from vacnic_amd.training import TrainArgs, build_models, forward_losses, to_device
-    cfg, vcfg = bart_large_vit_l14(dropout=0.0)
+    cfg, vcfg = bart_large_vit_l14(dropout=0.0, attention_dropout=0.0, activation_dropout=0.0)
     model, guide, _ = build_models(cfg, vcfg, init="device", seed=5)
     model.train()
     args = TrainArgs()
@@ -828,7 +828,7 @@ def test_whole_step_hipgraph_replays_like_eager():
 
 
 def test_attention_and_activation_dropout_on_the_operator_surface():
-    """config.attention_dropout / activation_dropout > 0 (MFULL:546,649,740,874; 0.0 in the hub configs, but part of the
+    """config.attention_dropout / activation_dropout > 0 (MFULL:546,649,740,874; 0.1 in the hub configs: part of the
     reference's surface): eval mode ignores them (same losses as the p = 0 model), training mode applies Philox masks
     that are reproducible from the seed, change with it, and are regenerated in backward (a second backward-capable step gives
     the same gradients); the whole step also trains (finite, decreasing loss) with all three dropouts on."""

@@ -41,8 +41,9 @@ def main():
         if M >= 1024 and N * Kd <= 4096 * 1024:
             t["wo"] = timeit(lambda: K.wgrad_group([(dy, x, d, None) for d in dws])) / 4 if M <= 4096 else timeit(
                 lambda: K.gemm(dy, x, N, Kd, M, out=dw, ldx=N, ldw=Kd, ldo=Kd, x_kstrided=True, w_kstrided=True, out_mode=2, split_k=K.wgrad_split(M, tiles)))
-        else:
-            t["wo"] = float("nan")
+        else:           # outputs beyond the grouped kernel's job size: the plain weight-gradient GEMM
+            t["wo"] = timeit(lambda: K.gemm(dy, x, N, Kd, M, out=dw, ldx=N, ldw=Kd, ldo=Kd, x_kstrided=True, w_kstrided=True, out_mode=2,
+                                            split_k=K.wgrad_split(M, tiles)))
         dyt = dy.t()
         t["wl"] = timeit(lambda: torch.matmul(dyt, x, out=dwl))
         f = lambda k: f"{fl / t[k] / 1e6:6.0f} ({t[k]:6.1f})"

@@ -84,6 +84,8 @@ parser.add_argument("--resume", type=str, default="", help="checkpoint written b
 PLM = {"facebook/bart-base": dict(d_model=768, encoder_layers=6, decoder_layers=6, encoder_attention_heads=12,
                                   decoder_attention_heads=12, encoder_ffn_dim=3072, decoder_ffn_dim=3072),
        "facebook/bart-large": dict(), "patrickvonplaten/bart-large-fp32": dict()}
+# from_pretrained(plm_type) (TRAIN:743) also inherits the checkpoint's dropout probabilities (attention / activation dropout 0.1 in
+# both hub configs — BartConfig's own defaults are 0.0): vacnic_amd.config.HUB_MODEL_DROPOUTS
 CLIP = {"ViT-B/32": dict(width=768, layers=12, patch_size=32, output_dim=512), "ViT-B/16": dict(width=768, layers=12, patch_size=16, output_dim=512),
         "ViT-L/14": dict(width=1024, layers=24, patch_size=14, output_dim=768)}
 
@@ -92,7 +94,7 @@ def run(args, batches=None):
     import torch
     import torch.distributed as dist
     from vacnic_amd import ops, streams, synthetic
-    from vacnic_amd.config import ClipVisionConfig, VacnicConfig
+    from vacnic_amd.config import HUB_MODEL_DROPOUTS, ClipVisionConfig, VacnicConfig
     from vacnic_amd.ddp import DistributedDataParallel
     from vacnic_amd.training import (FusedAdamW, PlannedTrainStep, TrainArgs, build_models, eval_epoch, gen_caption_from_loader_bart, to_device,
                                      train_step)
@@ -113,7 +115,7 @@ def run(args, batches=None):
                        max_ner_type_len=args.max_ner_type_len, max_ner_type_len_gt=args.max_ner_type_len_gt,
                        only_image=args.only_image, clip_width=vkw["width"], prompt_mlp_type=args.prompt_mlp_type, map_size=args.map_size,
                        init_attn_weight=args.init_attn_weight,
-                       **PLM[args.plm_type]).validate()
+                       **PLM[args.plm_type], **HUB_MODEL_DROPOUTS[args.plm_type]).validate()
     vcfg = ClipVisionConfig(**vkw)
     model, guide, _ = build_models(cfg, vcfg, device="cuda", seed=int(args.seed) % (2 ** 31), init="device")
     # Steps per epoch: the reference derives num_training_steps from the dataset (num_epoch * train_size / batch, TRAIN:99); with

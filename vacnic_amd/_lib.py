@@ -37,7 +37,8 @@ def _struct(name, fields):
 GemmArgs = _struct("vacnic_gemm_args", [
     ("x", vp), ("w", vp), ("bias", vp), ("out", vp), ("preact", vp), ("dact_src", vp), ("residual", vp), ("xsum", vp),
     ("M", i64), ("N", i64), ("K", i64), ("ldx", i64), ("ldw", i64), ("ldo", i64),
-    ("x_kstrided", i32), ("w_kstrided", i32), ("act", i32), ("out_mode", i32), ("split_k", i32), ("alpha", f32), ("tile_hint", i32)])
+    ("x_kstrided", i32), ("w_kstrided", i32), ("act", i32), ("out_mode", i32), ("split_k", i32), ("alpha", f32), ("tile_hint", i32),
+    ("workspace", vp), ("workspace_bytes", i64), ("counters", vp), ("counters_len", i64)])
 
 GemvLnArgs = _struct("vacnic_gemv_ln_args", [
     ("x", vp), ("residual", vp), ("gamma", vp), ("beta", vp), ("ln_out", vp), ("w", vp), ("bias", vp), ("out", vp),
@@ -178,7 +179,8 @@ _PLAIN_FNS = {
     "vacnic_beam_step": [C.POINTER(BeamState), vp, vp, i32, i32, vp],
 }
 EXPORTED = sorted(list(_STRUCT_FNS) + list(_PLAIN_FNS) + ["vacnic_last_error_string", "vacnic_version", "vacnic_decoder_step_sync_bytes", "vacnic_decoder_step_slots_bytes",
-                                                            "vacnic_plan_begin", "vacnic_plan_size", "vacnic_plan_mark"])
+                                                            "vacnic_plan_begin", "vacnic_plan_size", "vacnic_plan_mark",
+                                                            "vacnic_gemm_workspace_bytes", "vacnic_gemm_counters"])
 
 for _name, _st in _STRUCT_FNS.items():
     _fn = getattr(lib, _name)          # AttributeError here = stale .so: fail loudly
@@ -202,6 +204,10 @@ lib.vacnic_plan_size.restype = C.c_int64
 lib.vacnic_plan_size.argtypes = [C.c_int64]
 lib.vacnic_plan_mark.restype = C.c_int64
 lib.vacnic_plan_mark.argtypes = []
+lib.vacnic_gemm_workspace_bytes.restype = C.c_int64
+lib.vacnic_gemm_workspace_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int64]
+lib.vacnic_gemm_counters.restype = C.c_int64
+lib.vacnic_gemm_counters.argtypes = [C.c_int64, C.c_int64]
 
 _VALUE_ERRORS = (1, 2, 3)   # bad shape / dtype / alignment -> ValueError like the reference's shape checks
 

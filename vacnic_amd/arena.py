@@ -115,7 +115,7 @@ class ParamArena:
     def bucket_slices(self, bucket_bytes=256 << 20):
         """contiguous [start, end) element ranges of the gradient arena, in REVERSE layout order
         (the order backward finishes them), for the DDP reducer."""
-        per = max(1, bucket_bytes // 4)
+        per = max(4, bucket_bytes // 16 * 4)          # whole 16-byte groups: a bucket is also a range of the vectorised AdamW kernel
         out, end = [], self.n
         while end > 0:
             start = max(0, end - per)

@@ -23,7 +23,7 @@ class VacnicConfig:
     scale_embedding: bool = False
     activation_function: str = "gelu"
     dropout: float = 0.1
-    attention_dropout: float = 0.0
+    attention_dropout: float = 0.0      # BartConfig's class defaults; the hub checkpoints carry their own (HUB_MODEL_DROPOUTS below)
     activation_dropout: float = 0.0
     init_std: float = 0.02
     # VACNIC ctor kwargs (MFULL:1881)
@@ -90,13 +90,27 @@ class ClipVisionConfig:
         return self.grid * self.grid + 1
 
 
+# Dropout probabilities that live in the hub checkpoints' config.json: the reference builds its model with
+# `BartForMultiModalGeneration.from_pretrained(plm_type)` (TRAIN:743), so it inherits THESE, not BartConfig's class defaults
+# (attention_dropout = activation_dropout = 0.0, which only bart-large-cnn / -xsum publish).  The files are unreadable offline
+# (SURVEY §8c); these are the published values of facebook/bart-base and facebook/bart-large (the fp32 re-upload copies
+# bart-large's).  NB the kernels quantise p to k/256 (0.1 -> 26/256 = 0.1016; DESIGN §2 "Dropout").
+HUB_MODEL_DROPOUTS = {
+    "facebook/bart-base": dict(dropout=0.1, attention_dropout=0.1, activation_dropout=0.1),
+    "facebook/bart-large": dict(dropout=0.1, attention_dropout=0.1, activation_dropout=0.1),
+    "patrickvonplaten/bart-large-fp32": dict(dropout=0.1, attention_dropout=0.1, activation_dropout=0.1),
+}
+
+
 def bart_large_vit_l14(**kw):
-    """BASELINE.json configs[1..2]: BART-large + CLIP ViT-L/14, full VACNIC."""
+    """BASELINE.json configs[1..2]: BART-large + CLIP ViT-L/14, full VACNIC, with the hub checkpoint's dropouts (keywords override)."""
+    kw = dict(HUB_MODEL_DROPOUTS["facebook/bart-large"], **kw)
     return VacnicConfig(clip_width=1024, **kw).validate(), ClipVisionConfig()
 
 
 def bart_base_vit_b32(**kw):
     """BASELINE.json configs[0]: BART-base + ViT-B/32 --only_image."""
+    kw = dict(HUB_MODEL_DROPOUTS["facebook/bart-base"], **kw)
     c = VacnicConfig(d_model=768, encoder_layers=6, decoder_layers=6, encoder_attention_heads=12,
                      decoder_attention_heads=12, encoder_ffn_dim=3072, decoder_ffn_dim=3072,
                      enc_fusion_layer=list(range(6)), dim_common=768, only_image=True, clip_width=768, **kw).validate()

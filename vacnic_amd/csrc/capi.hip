@@ -4,7 +4,10 @@
 
 static thread_local char g_err[512] = "ok";
 
+namespace vplan { thread_local bool failed = false; }
+
 void vacnic_set_error(const char* fmt, ...) {
+  vplan::failed = true;
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
@@ -29,31 +32,45 @@ extern "C" int vacnic_version(void) { return 100; }
 // a replay there to interleave work of its own (the RCCL bucket launches of the DDP reducer).
 #include <vector>
 #include <mutex>
+#include <thread>
+#include <atomic>
 
 namespace vplan {
 struct Plan { std::vector<std::function<int()>> cmds; bool open = false; };
+static std::mutex g_mu;                          // plan table (begin / end / destroy / lookup); a recording itself is single-threaded
 static std::vector<Plan*> g_plans;
-static Plan* g_rec = nullptr;
+static std::atomic<Plan*> g_rec{nullptr};
+static std::thread::id g_rec_tid;                // written before g_rec is published, read only when g_rec is non-null
 thread_local int depth = 0;
-bool active() { return g_rec != nullptr; }
-void push(std::function<int()> f) { g_rec->cmds.push_back(std::move(f)); }
-static Plan* get(int64_t h) { return (h >= 0 && h < (int64_t)g_plans.size()) ? g_plans[(size_t)h] : nullptr; }
+// recording is bound to the thread that began it: a C-ABI call from any other thread (an autograd worker, a loader thread) while a
+// plan is open launches normally and is NOT frozen into the plan
+bool active() { return g_rec.load(std::memory_order_acquire) != nullptr && g_rec_tid == std::this_thread::get_id(); }
+void push(std::function<int()> f) { g_rec.load(std::memory_order_relaxed)->cmds.push_back(std::move(f)); }
+size_t size() { return g_rec.load(std::memory_order_relaxed)->cmds.size(); }
+void truncate(size_t n) { auto& c = g_rec.load(std::memory_order_relaxed)->cmds; if (n < c.size()) c.resize(n); }
+static Plan* get(int64_t h) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  return (h >= 0 && h < (int64_t)g_plans.size()) ? g_plans[(size_t)h] : nullptr;
+}
 }  // namespace vplan
 
 extern "C" int64_t vacnic_plan_begin(void) {
-  if (vplan::g_rec) { vacnic_set_error("plan_begin: a plan is already being recorded"); return -1; }
+  std::lock_guard<std::mutex> lk(vplan::g_mu);
+  if (vplan::g_rec.load()) { vacnic_set_error("plan_begin: a plan is already being recorded"); return -1; }
   vplan::Plan* p = new vplan::Plan();
   p->open = true;
   vplan::g_plans.push_back(p);
-  vplan::g_rec = p;
+  vplan::g_rec_tid = std::this_thread::get_id();
+  vplan::g_rec.store(p, std::memory_order_release);
   return (int64_t)vplan::g_plans.size() - 1;
 }
 
 extern "C" int vacnic_plan_end(int64_t h) {
   vplan::Plan* p = vplan::get(h);
-  VCHECK(p && p == vplan::g_rec, VACNIC_BAD_SHAPE, "plan_end: plan %ld is not the one being recorded", (long)h);
+  VCHECK(p && p == vplan::g_rec.load() && vplan::g_rec_tid == std::this_thread::get_id(), VACNIC_BAD_SHAPE,
+         "plan_end: plan %ld is not the one this thread is recording", (long)h);
   p->open = false;
-  vplan::g_rec = nullptr;
+  vplan::g_rec.store(nullptr, std::memory_order_release);
   return VACNIC_OK;
 }
 
@@ -62,12 +79,12 @@ extern "C" int64_t vacnic_plan_size(int64_t h) {
   return p ? (int64_t)p->cmds.size() : -1;
 }
 
-extern "C" int64_t vacnic_plan_mark(void) { return vplan::g_rec ? (int64_t)vplan::g_rec->cmds.size() : -1; }
+extern "C" int64_t vacnic_plan_mark(void) { return vplan::active() ? (int64_t)vplan::size() : -1; }
 
 extern "C" int vacnic_plan_replay(int64_t h, int64_t first, int64_t last) {
   vplan::Plan* p = vplan::get(h);
   VCHECK(p && !p->open, VACNIC_BAD_SHAPE, "plan_replay: plan %ld does not exist or is still being recorded", (long)h);
-  VCHECK(!vplan::g_rec, VACNIC_UNSUPPORTED, "plan_replay: not while another plan is being recorded");
+  VCHECK(!vplan::active(), VACNIC_UNSUPPORTED, "plan_replay: not while this thread is recording a plan");
   VCHECK(first >= 0 && first <= last && last <= (int64_t)p->cmds.size(), VACNIC_BAD_SHAPE, "plan_replay: range [%ld, %ld) outside the plan's %ld commands",
          (long)first, (long)last, (long)p->cmds.size());
   for (int64_t i = first; i < last; ++i)
@@ -77,7 +94,8 @@ extern "C" int vacnic_plan_replay(int64_t h, int64_t first, int64_t last) {
 
 extern "C" int vacnic_plan_destroy(int64_t h) {
   vplan::Plan* p = vplan::get(h);
-  VCHECK(p && p != vplan::g_rec, VACNIC_BAD_SHAPE, "plan_destroy: plan %ld does not exist or is being recorded", (long)h);
+  VCHECK(p && p != vplan::g_rec.load(), VACNIC_BAD_SHAPE, "plan_destroy: plan %ld does not exist or is being recorded", (long)h);
+  std::lock_guard<std::mutex> lk(vplan::g_mu);
   delete p;
   vplan::g_plans[(size_t)h] = nullptr;
   return VACNIC_OK;
@@ -93,6 +111,8 @@ extern "C" int vacnic_stream_fence(void* src, void* dst) {
   static hipEvent_t ring[RING];
   static bool made[RING];
   static unsigned next = 0;
+  static std::mutex mu;                          // slot choice + record/wait pair: fences may come from more than one host thread
+  std::lock_guard<std::mutex> lk(mu);
   const unsigned i = next++ % RING;
   if (!made[i]) {
     if (hipEventCreateWithFlags(&ring[i], hipEventDisableTiming) != hipSuccess) { vacnic_set_error("stream_fence: hipEventCreate failed"); return VACNIC_HIP_ERROR; }

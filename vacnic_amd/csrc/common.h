@@ -43,10 +43,19 @@ static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0;
 // C-ABI function calling another) is recorded once, by the outermost call.
 #include <functional>
 namespace vplan {
-bool active();                                   // a plan is being recorded (by this process's launching thread)
+bool active();                                   // a plan is being recorded BY THIS THREAD (the one that called vacnic_plan_begin)
 void push(std::function<int()> f);
+size_t size();                                   // commands recorded so far
+void truncate(size_t n);                         // forget the commands recorded after the first n
 extern thread_local int depth;
-struct Guard { Guard() { ++depth; } ~Guard() { --depth; } };
+extern thread_local bool failed;                 // vacnic_set_error was called inside the outermost entry point in progress
+// An entry point records its closure on entry and runs; if it then reports an error (every error path goes through
+// vacnic_set_error), the outermost Guard takes the command back, so a plan never holds a call that failed while recording.
+struct Guard {
+  size_t mark;
+  Guard() : mark(0) { if (++depth == 1) { failed = false; mark = active() ? size() : 0; } }
+  ~Guard() { if (--depth == 0 && failed && active()) truncate(mark); }
+};
 inline bool outermost() { return depth == 1 && active(); }
 }  // namespace vplan
 #define VPLAN_REC(fn, ...)                                                   \

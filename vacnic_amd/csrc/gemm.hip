@@ -297,6 +297,18 @@ static double cfg_cost(const TileCfg& c, int64_t M, int64_t N, int64_t kper, int
 
 static int gemm_one(const vacnic_gemm_args* a, int hint, void* stream, int ce_mode = 0, int ce_col0 = 0);
 
+// fix-up buffers: partial tiles are padded to whole tiles; the bound covers every configuration (64-row tiles pad M the least,
+// 256 x 256 the most), so the caller need not know which one a launch picks
+extern "C" int64_t vacnic_gemm_workspace_bytes(int64_t M, int64_t N, int64_t split_k) {
+  if (M <= 0 || N <= 0 || split_k <= 1) return 0;
+  const int64_t mp = (M + 255) / 256 * 256, np = (N + 255) / 256 * 256;
+  return mp * np * 4 * split_k;
+}
+extern "C" int64_t vacnic_gemm_counters(int64_t M, int64_t N) {
+  if (M <= 0 || N <= 0) return 0;
+  return ((M + 63) / 64) * ((N + 127) / 128);
+}
+
 extern "C" int vacnic_gemm_bf16(const vacnic_gemm_args* a, void* stream) {
   VPLAN_REC_STRUCT(vacnic_gemm_bf16, a, stream);
   VCHECK(a && a->x && a->w && a->out, VACNIC_BAD_SHAPE, "gemm: null operand");
@@ -347,7 +359,14 @@ static int gemm_one(const vacnic_gemm_args* a, int tile_hint, void* stream, int 
   VCHECK(aligned16(a->x) && aligned16(a->w), VACNIC_MISALIGNED, "gemm: x/w must be 16-byte aligned");
   VCHECK(a->out_mode >= 0 && a->out_mode <= 2, VACNIC_BAD_DTYPE, "gemm: bad out_mode %d", a->out_mode);
   const int split = a->split_k < 1 ? 1 : a->split_k;
-  VCHECK(split == 1 || a->out_mode == 2, VACNIC_UNSUPPORTED, "gemm: split_k needs out_mode 2");
+  VCHECK(split == 1 || a->out_mode == 2 || a->workspace, VACNIC_UNSUPPORTED, "gemm: split_k needs out_mode 2 or a fix-up workspace");
+  if (a->workspace && split > 1) {
+    VCHECK(a->counters && aligned16(a->workspace), VACNIC_BAD_SHAPE, "gemm: the split-K fix-up needs `counters` and a 16-byte aligned workspace");
+    VCHECK(a->workspace_bytes >= vacnic_gemm_workspace_bytes(a->M, a->N, split) && a->counters_len >= vacnic_gemm_counters(a->M, a->N), VACNIC_BAD_SHAPE,
+           "gemm: fix-up workspace %ld B / %ld counters, need %ld B / %ld", (long)a->workspace_bytes, (long)a->counters_len,
+           (long)vacnic_gemm_workspace_bytes(a->M, a->N, split), (long)vacnic_gemm_counters(a->M, a->N));
+    VCHECK(tile_hint != 8 && !ce_mode, VACNIC_UNSUPPORTED, "gemm: no split-K fix-up in the skinny / cross-entropy kernels");
+  }
   VCHECK(a->bias == nullptr || aligned16(a->bias), VACNIC_MISALIGNED, "gemm: bias must be 16-byte aligned");
   VCHECK(a->ldo >= a->N, VACNIC_BAD_SHAPE, "gemm: ldo < N");
   VCHECK(!a->xsum || ce_mode || (a->x_kstrided && a->w_kstrided), VACNIC_UNSUPPORTED,
@@ -380,6 +399,8 @@ static int gemm_one(const vacnic_gemm_args* a, int tile_hint, void* stream, int 
   p.alpha = a->alpha;
   p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
   p.tiles_m = p.tiles_n = 0;
+  p.ws = (a->workspace && zsplits > 1) ? (float*)a->workspace : nullptr;
+  p.cnt = p.ws ? a->counters : nullptr;
   hipStream_t s = (hipStream_t)stream;
   if (tile_hint == 8) {     // skinny-M kernel (chosen by vacnic_gemm_bf16 for M <= 8, or forced by the caller)
     VCHECK(a->M <= 8 && !a->x_kstrided && !a->w_kstrided && zsplits == 1 && !a->preact && !a->dact_src && !a->residual && !a->xsum &&

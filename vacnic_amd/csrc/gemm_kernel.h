@@ -22,6 +22,8 @@ struct GemmP {
   unsigned x_bytes, w_bytes;
   int tiles_m, tiles_n;
   int ce_col0;          // out_mode 3 / 4: global vocabulary index of this launch's column 0 (targets are global ids)
+  float* ws;            // split-K with ordered fix-up (see gemm_tile): fp32 partial tiles [tile][split][BM*BN]; nullptr = atomics
+  unsigned* cnt;        // one arrival counter per output tile (zero before the launch, zero again after it)
   int debug;            // profiling aid (tile_hint >= 1000): bit0 skip the global stores, bit1 skip the K loop, bit2 skip the epilogue, bit3 return at once, bit4 fp32 staged epilogue, bit5 no LDS-DMA in the loop, bit7 no fragment reads
 };
 
@@ -239,7 +241,7 @@ __device__ __forceinline__ void wait_vm_lgkm() { asm volatile("s_waitcnt vmcnt(%
 // One output tile: rows [m0, m0 + BM) x columns [n0, n0 + BN), reduction slice `zsplit`.  `tn` = this tile's column index inside
 // its row panel and p.tiles_n the number of tiles that share the panel (the xsum K-steps are dealt round-robin over them).
 template <int BM, int BN, int WM, int WN, int BKT, int NSTAGE, bool PIPE, bool XKS, bool WKS, bool CE>
-__device__ __forceinline__ void gemm_tile(const GemmP& p, const int m0, const int n0, const int tn, const int zsplit) {
+__device__ __forceinline__ void gemm_tile(const GemmP& p, const int m0, const int n0, const int tn, const int zsplit, const int tile_id = 0) {
   constexpr int NWAVE = WM * WN, NTHR = 64 * NWAVE;
   constexpr int TM = BM / WM, TN = BN / WN;             // per-wave output sub-tile
   constexpr int FA = TM / 16, FB = TN / 16;             // MFMA tiles per wave along m / n
@@ -460,6 +462,55 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, const int m0, const in
   }
 
   if (p.debug & 4) { if (acc[0][0][0] == 12345.678f) ((float*)p.out)[0] = 0.f; return; }
+  // ---- split-K with an ORDERED FIX-UP instead of atomics (p.ws != nullptr): every K-slice workgroup of a tile deposits its fp32
+  // partial tile in the workspace and takes a ticket; the LAST one to arrive sums all slices in slice order 0 .. S-1 — a fixed
+  // order whoever comes last, so the result is bitwise reproducible — and runs the ordinary epilogue ONCE (bias, activation,
+  // residual, bf16 or fp32 output, accumulate as a plain read-modify-write).  Nobody waits: the other workgroups leave after their
+  // deposit.  The partials cross XCDs, so they travel as sc1 stores / loads (write-through, miss-always in the XCD's L2; complete
+  // when vmcnt says so — the decoder-step kernel's hand-over, decstep.hip) and the ticket is a relaxed agent-scope atomic: no
+  // cache write-back / invalidate (20-35 us apiece on this part).  Layout: a thread's own accumulator registers, 16 bytes per
+  // lane per store — fully coalesced, and the summing workgroup's threads read back exactly the elements they own.
+  const bool fix = p.ws != nullptr && p.split_k > 1;
+  if (fix) {
+    constexpr int NACC = FA * FB, COH = 16;
+    constexpr unsigned TILE_BYTES = (unsigned)BM * BN * 4u;
+    float* wtile = p.ws + (size_t)tile_id * p.split_k * ((size_t)BM * BN);
+    {
+      __amdgpu_buffer_rsrc_t ps = __builtin_amdgcn_make_buffer_rsrc((void*)(wtile + (size_t)zsplit * ((size_t)BM * BN)), 0, TILE_BYTES, 0x00020000);
+#pragma unroll
+      for (int b = 0; b < FB; ++b)
+#pragma unroll
+        for (int a = 0; a < FA; ++a)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[b][a]), ps, (unsigned)(((b * FA + a) * NTHR + tid) * 16), 0, COH);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this thread's deposit is in memory
+    __syncthreads();                                     // ... and everybody's
+    int* s_ticket = (int*)smem;
+    if (tid == 0) *s_ticket = (int)__hip_atomic_fetch_add(p.cnt + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int ticket = *s_ticket;
+    if (ticket != p.split_k - 1) return;
+    if (tid == 0) __hip_atomic_store(p.cnt + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every slice has arrived: clean for the next launch
+    constexpr int BATCH = NACC < 8 ? NACC : 8;
+#pragma unroll 1
+    for (int z = 0; z < p.split_k; ++z) {
+      __amdgpu_buffer_rsrc_t ps = __builtin_amdgcn_make_buffer_rsrc((void*)(wtile + (size_t)z * ((size_t)BM * BN)), 0, TILE_BYTES, 0x00020000);
+#pragma unroll
+      for (int i0 = 0; i0 < NACC; i0 += BATCH) {
+        u32x4 v[BATCH];
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(ps, (unsigned)(((i0 + i) * NTHR + tid) * 16), 0, COH);
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) {
+          const f32x4 f = __builtin_bit_cast(f32x4, v[i]);
+          const int b = (i0 + i) / FA, a = (i0 + i) % FA;
+          if (z == 0) acc[b][a] = f; else acc[b][a] += f;
+        }
+      }
+    }
+    __syncthreads();                                     // the ticket word's readers are done before the epilogue reuses the LDS
+  }
+  const bool split_atomic = p.split_k > 1 && !fix;        // K slices meet in fp32 atomics on the output
   // ---- direct epilogue for the common plain case (bf16 out, bias + activation only): each lane owns 4 consecutive n of
   // one m per accumulator tile -> bias as one 16-byte load, pack with v_cvt_pk_bf16_f32, one 8-byte store.  No LDS
   // round trip, no barriers; the 32-byte row pieces of the four n-groups are merged by the L2.
@@ -623,7 +674,7 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, const int m0, const in
   constexpr int CLD = BN + 4;
   constexpr int PASSES = (BM + 63) / 64;
   const bool vec_ok = (p.ldo & 7) == 0;
-  const bool add_bias = zsplit == 0;
+  const bool add_bias = zsplit == 0 || fix;
   float bia[8];
   // A pass stages 64 tile rows: RPWM = 64/WM rows from EACH wave row-group, so that every wave deposits in every pass (the
   // LDS store path has two halves, SIMDs {0,1} and {2,3}; a pass fed by the waves of one wm only ran it at half rate).
@@ -714,7 +765,7 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, const int m0, const in
       continue;
     }
     }
-    if (p.out_mode == 2 && p.split_k > 1) {
+    if (p.out_mode == 2 && split_atomic) {
       // split-K accumulate: f32 atomics shaped as 256 contiguous bytes per wave-instruction (one row, 64
       // consecutive columns) — the shape the memory-side atomic units run at full rate on
       constexpr int RPW = 64 / NWAVE;
@@ -817,8 +868,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
   const int tm = bid / p.tiles_n, tn = bid - tm * p.tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
-  gemm_tile<BM, BN, WM, WN, BKT, NSTAGE, PIPE, XKS, WKS, CE>(p, tm * BM, tn * BN, tn, zsplit);
+  gemm_tile<BM, BN, WM, WN, BKT, NSTAGE, PIPE, XKS, WKS, CE>(p, tm * BM, tn * BN, tn, zsplit, bid);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -861,7 +911,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_group_kernel(GroupP g) {
   p.act = VACNIC_ACT_NONE; p.out_mode = 2; p.split_k = 1; p.k_per_split = g.k_per_phase;
   p.alpha = 1.0f; p.x_bytes = u.x_bytes; p.w_bytes = u.w_bytes;
   p.tiles_m = GROUP_UT; p.tiles_n = min(GROUP_UT, (u.N - u.un0 + BN - 1) / BN);
-  p.ce_col0 = 0; p.debug = g.debug;
+  p.ce_col0 = 0; p.debug = g.debug; p.ws = nullptr; p.cnt = nullptr;
   gemm_tile<BM, BN, WM, WN, BKT, NSTAGE, PIPE, true, true, false>(p, m0, n0, tn, g.kphase);
 }
 

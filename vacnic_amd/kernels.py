@@ -76,6 +76,11 @@ def _p(t):
     return t.data_ptr()
 
 
+def recording():
+    """a launch plan is being recorded by this process (vacnic_plan_begin .. vacnic_plan_end)."""
+    return int(_lib.lib.vacnic_plan_mark()) >= 0
+
+
 def fence(src_raw, dst_raw):
     """stream `dst` waits for everything enqueued on stream `src` so far (raw hipStream_t handles) — the recordable form of
     event.record(src); dst.wait_event(event) (vacnic_stream_fence): cross-stream edges are part of a launch plan."""
@@ -105,10 +110,32 @@ def _load_tuned():
 _load_tuned()
 
 
+_FIX = {}                 # launch stream -> [workspace (uint8), counters (int32, all zero between launches)]
+_FIX_OLD = []             # outgrown workspaces: kernels already enqueued may still use them
+
+
+def _fix_buffers(stream, M, N, split_k):
+    """split-K fix-up buffers of the launch stream: launches on ONE stream run in order, so they share a workspace that only
+    grows (persistent: the same addresses at every replay of a launch plan or a hipGraph), and the arrival counters, which every
+    launch leaves zeroed.  Kept out of torch's per-step allocations on purpose."""
+    need = int(_lib.lib.vacnic_gemm_workspace_bytes(M, N, split_k))
+    ncnt = int(_lib.lib.vacnic_gemm_counters(M, N))
+    ent = _FIX.get(stream)
+    if ent is None or ent[0].numel() < need or ent[1].numel() < ncnt:
+        ws = torch.empty(max(need, ent[0].numel() if ent else 0, 64 << 20), device="cuda", dtype=torch.uint8)
+        cnt = torch.zeros(max(ncnt, ent[1].numel() if ent else 0, 4096), device="cuda", dtype=torch.int32)
+        if ent is not None:
+            _FIX_OLD.append(ent)
+        torch.cuda.current_stream().synchronize()      # (rare: first use / growth) the zero fill ran on torch's stream, the launch may not
+        ent = _FIX[stream] = [ws, cnt]
+    return ent
+
+
 def gemm(x, w, M, N, K, *, bias=None, out=None, ldx=None, ldw=None, ldo=None, x_kstrided=False, w_kstrided=False,
-         act=None, out_mode=0, split_k=1, alpha=1.0, preact=None, dact_src=None, residual=None, tile_hint=0, xsum=None):
+         act=None, out_mode=0, split_k=1, alpha=1.0, preact=None, dact_src=None, residual=None, tile_hint=0, xsum=None, fixup=False):
     """out[m][n] = epi(alpha * sum_k X(m,k) W(n,k) + bias[n]) — see include/vacnic_hip.h.
-    tile_hint 0: measured winner for this exact shape if gemm_tuned.json has one, else the C-side cost model; -1: cost model."""
+    tile_hint 0: measured winner for this exact shape if gemm_tuned.json has one, else the C-side cost model; -1: cost model.
+    fixup: split_k > 1 through the ordered fix-up (no atomics, bitwise reproducible, any out_mode) instead of fp32 atomics."""
     if out is None:
         out = torch.empty((M, N), device=x.device, dtype=BF16 if out_mode == 0 else torch.float32)
     ldx = ldx if ldx is not None else (M if x_kstrided else K)
@@ -125,10 +152,16 @@ def gemm(x, w, M, N, K, *, bias=None, out=None, ldx=None, ldw=None, ldo=None, x_
                 split_k = t[1] if _SPLIT_SCALE == 1.0 else max(1, min(32, int(t[1] * _SPLIT_SCALE)))
     if tile_hint < 0:
         tile_hint = 0
-    call_struct("vacnic_gemm_bf16", stream=_stream(), x=_p(x), w=_p(w), bias=_p(bias), out=_p(out), preact=_p(preact),
+    st = _stream()
+    ws = wsb = cnt = cntn = None
+    if fixup and split_k > 1:
+        wbuf, cbuf = _fix_buffers(st, M, N, split_k)
+        ws, wsb, cnt, cntn = wbuf.data_ptr(), wbuf.numel(), cbuf.data_ptr(), cbuf.numel()
+    call_struct("vacnic_gemm_bf16", stream=st, x=_p(x), w=_p(w), bias=_p(bias), out=_p(out), preact=_p(preact),
                 dact_src=_p(dact_src), residual=_p(residual), xsum=_p(xsum), M=M, N=N, K=K, ldx=ldx, ldw=ldw, ldo=ldo,
                 x_kstrided=int(x_kstrided), w_kstrided=int(w_kstrided), act=ACT[act], out_mode=out_mode,
-                split_k=split_k, alpha=alpha, tile_hint=tile_hint)
+                split_k=split_k, alpha=alpha, tile_hint=tile_hint, workspace=ws, workspace_bytes=wsb or 0, counters=cnt,
+                counters_len=cntn or 0)
     return out
 
 

@@ -162,7 +162,7 @@ class BartEncoderLayer(nn.Module):
         self.dropout = config.dropout
         if config.activation_function != "gelu":
             raise NotImplementedError("activation_function must be gelu (bart-base/large)")
-        self.activation_dropout = config.activation_dropout              # MFULL:580 (0.0 in the hub configs)
+        self.activation_dropout = config.activation_dropout              # MFULL:580 (0.1 in the bart-base / bart-large hub configs: config.HUB_MODEL_DROPOUTS)
         self.fc1 = nn.Linear(d, config.encoder_ffn_dim)
         self.fc2 = nn.Linear(config.encoder_ffn_dim, d)
         self.final_layer_norm = nn.LayerNorm(d)

@@ -58,7 +58,20 @@ class LinearSpec:
 
 
 def _c(t):
-    return t if t.is_contiguous() else t.contiguous()
+    """t, contiguous.  A strided bf16 view (unit inner stride, <= 3-D) is packed by OUR copy kernel on the op's launch stream:
+    Tensor.contiguous() would be an ATen kernel on torch's current stream — not the side stream a backward node launches on, and
+    invisible to a recorded launch plan (a replay would then read stale data)."""
+    if t.is_contiguous():
+        return t
+    if t.is_cuda and t.dtype == BF16 and t.stride(-1) == 1 and 2 <= t.dim() <= 3:
+        t3 = t if t.dim() == 3 else t.unsqueeze(0)
+        out = torch.empty(t3.shape, device=t.device, dtype=BF16)
+        K.copy3d(t3, out, t3.shape[0], t3.shape[1], t3.shape[2])
+        return out.view(t.shape)
+    if K._OVERRIDE is not None or K.recording():
+        raise RuntimeError(f"vacnic_amd.ops: cannot pack a {t.dtype} view with strides {t.stride()} without an ATen kernel "
+                           "(side-stream launch or launch-plan recording in progress)")
+    return t.contiguous()
 
 
 def _bw(fn):
@@ -189,6 +202,15 @@ class _WgradQueue:
         for M in list(self.by_m):
             self._launch(M)
 
+    def reset(self):
+        """forget everything queued: a backward pass that RAISED never runs the engine's final callbacks, so `armed` would stay
+        set and the failed pass's jobs (stale dy / x tensors) would ride into the next step's launches.  train_step calls this
+        before every forward and flush() right after backward()."""
+        self.by_m.clear()
+        self.units.clear()
+        self.dst.clear()
+        self.armed = False
+
 
 _WGQ = _WgradQueue()
 
@@ -196,6 +218,15 @@ _WGQ = _WgradQueue()
 def flush_wgrads():
     """launch every deferred weight gradient now (the autograd engine does this at the end of backward)."""
     _WGQ.flush()
+
+
+def begin_step():
+    """start of a training step: drop whatever a failed previous step left in the deferred weight-gradient queue, and release the
+    side-stream keep-list behind a join if that step never reached its own (an aborted step, a grad-enabled forward without a
+    backward: the list would otherwise pin every branch / aux / comm-stream activation)."""
+    _WGQ.reset()
+    if streams.pending_keep():
+        streams.join_all()
 
 
 def _groupable(dy2d, x2d, spec, M):
@@ -279,6 +310,9 @@ class LinearFn(Function):
     def backward(ctx, dy, dskip=None):
         (x2,) = ctx.saved_tensors
         spec, M = ctx.spec, ctx.M
+        if dy is None:                        # only the skip output was differentiated: this Linear contributes nothing
+            ddp.done(spec.wgrad, spec.bgrad)
+            return dskip, None, None, None, None, None
         dy2 = _c(dy).view(M, spec.N)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -305,8 +339,8 @@ def linear_skip(x, anchor, spec):
 class Mlp2Fn(Function):
     """y = W2 dropout(act(W1 x + b1), p_act) + b2 — every two-layer block on the path: text/img/face FFN (MFULL:647-664,
     738-741), name-prefix FFN on the flat view (:682-687), ClipCap prompt MLP (MFULL:111-123), ViT MLP.
-    The activation backward is fused into the dgrad GEMM epilogue (dact_src).  p_act > 0 (config.activation_dropout; 0.0 in
-    bart-base/large): an in-place Philox dropout pass over the hidden activations, repeated on their gradient in backward."""
+    The activation backward is fused into the dgrad GEMM epilogue (dact_src).  p_act > 0 (config.activation_dropout; 0.1 in the
+    bart-base / bart-large hub configs): an in-place Philox dropout pass over the hidden activations, repeated on their gradient in backward."""
 
     @staticmethod
     def forward(ctx, x, anchor, s1, s2, act, ge, skip=False, p_act=0.0, seed=0):
@@ -333,6 +367,9 @@ class Mlp2Fn(Function):
     def backward(ctx, dy, dskip=None):
         x2, u, h = ctx.saved_tensors
         s1, s2, act, M = ctx.s1, ctx.s2, ctx.act, ctx.M
+        if dy is None:                        # only the skip output was differentiated
+            ddp.done(s1.wgrad, s1.bgrad, s2.wgrad, s2.bgrad)
+            return dskip, None, None, None, None, None, None, None, None
         dy2 = _c(dy).view(M, s2.N)
         if s2.N % 8:                                   # 20-wide name-prefix output: give the GEMMs 16-byte rows
             dy2 = K.pad_cols(dy2, (s2.N + 7) // 8 * 8)

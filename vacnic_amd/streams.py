@@ -88,6 +88,11 @@ def keep(*tensors):
         k.clear()
 
 
+def pending_keep():
+    """number of tensors still held for the side streams (0 right after join_all)."""
+    return len(_state["keep"])
+
+
 def branch_stream():
     """stream of the encoder layer's small-token branches (image / face / name streams of MFULL:647-691: a dozen GEMMs over
     20-80 tokens per sample that occupy a fraction of the GPU) — they run beside the text self-attention block of the same

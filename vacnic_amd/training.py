@@ -268,11 +268,13 @@ def train_step(model, guide, optimizer, batch, args: TrainArgs, ready=None, towe
     net = model.module if isinstance(model, DistributedDataParallel) else model
     if not net.training:
         net.train()
+    ops.begin_step()                         # (a previous step that raised must not leak queued weight gradients into this one)
     total, out4, _ = forward_losses(model, guide, batch, args, ready, towers)
     with torch.autograd.set_multithreading_enabled(False):     # one device: the engine's worker-thread hop only costs host time
         # explicit unit gradient from a persistent constant: backward()'s default ones_like(total) is a fill kernel into a fresh
         # block per step — the one ATen kernel left inside the step (tools/aten_in_step.py), invisible to a launch plan
         total.backward(ops.const_one(total.device))
+    ops.flush_wgrads()                       # normally empty (the engine's end-of-backward callback already ran)
     streams.join_all()                       # weight-gradient side stream -> compute stream
     if _PLAN is not None and _PLAN.towers is not None:
         _PLAN.mark("backward_done")          # (the host can start the next step's guide graph behind this point)
@@ -423,9 +425,16 @@ class PlannedTrainStep:
         try:
             with torch.cuda.use_mem_pool(self.pool):
                 self.out4 = train_step(model, guide, optimizer, self.static, args, None, towers)
-        finally:
+        except BaseException:
+            # a recording that raised leaves neither a half-recorded plan nor its private pool behind
             _PLAN = None
-            _lib.check(_lib.lib.vacnic_plan_end(self.handle))
+            _lib.lib.vacnic_plan_end(self.handle)
+            _lib.lib.vacnic_plan_destroy(self.handle)
+            self.handle = None
+            self.pool = None
+            raise
+        _PLAN = None
+        _lib.check(_lib.lib.vacnic_plan_end(self.handle))
         torch.cuda.synchronize()
         self.commands = int(_lib.lib.vacnic_plan_size(self.handle))
 
