@@ -86,6 +86,14 @@ typedef struct {
   int64_t workspace_bytes;
   uint32_t* counters;
   int64_t counters_len;           /* words */
+  /* activation dropout fused into the epilogue — nn.functional.dropout(act(fc1 x), p=activation_dropout) of the FFN blocks
+     (MFULL:649,660,684,740,874) in the forward GEMM (applied after the activation) and the same mask on the gradient in the
+     dgrad GEMM that carries dact_src (applied after act'): drop_p in (0, 1), quantised to 1/256; the mask is the function of
+     (drop_seed ^ f(*drop_seed_dev), element index m * N + n) that vacnic_dropout_bf16 evaluates, so nothing is stored.
+     Needs out_mode 0, ldo == N and N % 16 == 0.  drop_p = 0: off. */
+  float drop_p;
+  uint64_t drop_seed;
+  const uint64_t* drop_seed_dev;
 } vacnic_gemm_args;
 int vacnic_gemm_bf16(const vacnic_gemm_args* a, void* stream);
 /* sizes of the split-K fix-up buffers for an M x N output (upper bounds over every tile configuration the library may pick) */
@@ -177,8 +185,9 @@ typedef struct {
 } vacnic_add_ln_fwd_args;
 int vacnic_add_ln_fwd(const vacnic_add_ln_fwd_args* a, void* stream);
 /* out[i] = x[i] * keep_i / (1 - p) on a flat bf16 array (in place allowed; n % 8 == 0): nn.functional.dropout(act(fc1 x),
- * p=activation_dropout) of the FFN blocks (MFULL:649,660,684,740,874).  Philox keep bits from (seed ^ f(*seed_dev), element
- * index) exactly as in add_ln: backward calls it again on the gradient with the same seed, nothing is stored. */
+ * p=activation_dropout) of the FFN blocks (MFULL:649,660,684,740,874) as a stand-alone pass — the same mask the GEMM epilogues
+ * apply when vacnic_gemm_args.drop_p is set: p quantised to 1/256, element i keeps iff byte i % 16 of Philox block i / 16 of
+ * (seed ^ f(*seed_dev)) is >= round(256 p).  Backward calls it on the gradient with the same seed; nothing is stored. */
 int vacnic_dropout_bf16(const void* x, void* out, int64_t n, float p_drop, uint64_t seed, const uint64_t* seed_dev, void* stream);
 
 /* backward: recomputes h = residual + dropout(x) from the saved INPUTS (x, residual) and the saved

@@ -494,6 +494,38 @@ def test_activation_dropout_kernel_and_mlp2(K):
     assert ((s2.wgrad - (dout.float().t() @ h.detach())).norm() / (dout.float().t() @ h.detach()).norm()).item() < 2e-2, "fc2's weight gradient sees the dropped activations"
 
 
+@pytest.mark.parametrize("hint", [64, 128, 256, 264])
+@pytest.mark.parametrize("M,N,K_", [(700, 512, 128), (96, 80, 256), (2048, 4096, 1024)])
+def test_gemm_fused_activation_dropout(K, hint, M, N, K_):
+    """activation dropout inside the GEMM epilogues (vacnic_gemm_args.drop_p): the forward Linear applies the mask after the
+    activation (with and without a saved pre-activation), the dgrad applies the SAME mask after act'; the mask is the one
+    vacnic_dropout_bf16 produces for the same (seed, device counter).  Every tile configuration (128 runs on the 64-row tiles)."""
+    from vacnic_amd import ops
+    if hint in (256, 264) and N < 256:
+        pytest.skip("256-row tiles need N >= 256")
+    p, seed = 0.1, 777
+    cnt = ops.Rng.device_counter(); cnt.fill_(5)
+    x = rnd(M, K_, seed=1); w = rnd(N, K_, scale=0.1, seed=2); b = rnd(N, dtype=torch.float32, seed=3)
+    mask = K.dropout_(torch.ones(M, N, device="cuda", dtype=torch.bfloat16), p, seed, cnt).float()
+    assert abs((mask != 0).float().mean().item() - (1 - 26 / 256)) < 0.01 and torch.allclose(mask[mask != 0], torch.tensor(256.0 / 230.0, device="cuda"), rtol=4e-3)
+    u = x.float() @ w.float().t() + b
+    pre = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    h = K.gemm(x, w, M, N, K_, bias=b, act="gelu", preact=pre, drop=(p, seed, cnt), tile_hint=hint)
+    close(pre, u, 1e-2, 1e-2, "saved pre-activation is not dropped")
+    close(h, torch.nn.functional.gelu(pre.float()) * mask, 1e-2, 1e-2, f"gelu then dropout, hint {hint}")
+    assert torch.equal(h == 0, (mask == 0) | (torch.nn.functional.gelu(pre.float()) * mask).bfloat16().eq(0)), "dropped positions are exact zeros"
+    h2 = K.gemm(x, w, M, N, K_, bias=b, act="gelu", drop=(p, seed, cnt), tile_hint=hint)             # no saved pre-activation (fp32-staged path)
+    close(h2, torch.nn.functional.gelu(u) * mask, 1.5e-2, 2e-2, "gelu then dropout without preact")
+    dy = rnd(M, 96, seed=5); w2 = rnd(96, N, scale=0.1, seed=6)
+    du = K.gemm(dy, w2, M, N, 96, w_kstrided=True, act="gelu", dact_src=pre, drop=(p, seed, cnt), tile_hint=hint)
+    uu = pre.float().requires_grad_(True)
+    (torch.nn.functional.gelu(uu) * mask).backward(dy.float() @ w2.float())
+    close(du, uu.grad, 2e-2, 2e-2, f"act' then the same mask, hint {hint}")
+    cnt.fill_(6)                                                  # the device counter is part of the key: fresh mask every step
+    assert not torch.equal(h, K.gemm(x, w, M, N, K_, bias=b, act="gelu", preact=pre, drop=(p, seed, cnt), tile_hint=hint))
+    cnt.zero_()
+
+
 def test_add_ln_dropout_consistency(K):
     R, D, p = 256, 1024, 0.1
     x = rnd(R, D, seed=1); res = torch.zeros(R, D, device="cuda", dtype=torch.bfloat16)

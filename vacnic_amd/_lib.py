@@ -38,7 +38,8 @@ GemmArgs = _struct("vacnic_gemm_args", [
     ("x", vp), ("w", vp), ("bias", vp), ("out", vp), ("preact", vp), ("dact_src", vp), ("residual", vp), ("xsum", vp),
     ("M", i64), ("N", i64), ("K", i64), ("ldx", i64), ("ldw", i64), ("ldo", i64),
     ("x_kstrided", i32), ("w_kstrided", i32), ("act", i32), ("out_mode", i32), ("split_k", i32), ("alpha", f32), ("tile_hint", i32),
-    ("workspace", vp), ("workspace_bytes", i64), ("counters", vp), ("counters_len", i64)])
+    ("workspace", vp), ("workspace_bytes", i64), ("counters", vp), ("counters_len", i64),
+    ("drop_p", f32), ("drop_seed", u64), ("drop_seed_dev", vp)])
 
 GemvLnArgs = _struct("vacnic_gemv_ln_args", [
     ("x", vp), ("residual", vp), ("gamma", vp), ("beta", vp), ("ln_out", vp), ("w", vp), ("bias", vp), ("out", vp),

@@ -107,21 +107,45 @@ __device__ __forceinline__ void drop_patch(const DropCtx& d, int q, int k, uint3
   const unsigned long long idx = d.bh_base + (unsigned long long)(q >> 2) * d.pk_per_row + (unsigned)(k >> 2);
   philox4x32((uint32_t)idx, (uint32_t)(idx >> 32), 0x41545444u, 0u, (uint32_t)d.seed, (uint32_t)(d.seed >> 32), w);
 }
-// keep factors of the 4 keys k0 .. k0+3 (k0 % 4 == 0) of query q
-__device__ __forceinline__ void drop_keys4(const DropCtx& d, int q, int k0, float m[4]) {
+// The four lanes of a QUAD hold four consecutive queries (forward, dQ) or keys (dK/dV) and, for each of the four row groups g of
+// a 32-row accumulator block, need the SAME 4 x 4 patch — one word (their query) or one byte column (their key) of it each.
+// So lane i of the quad generates only the patch of group g = i, and the words travel by quad_perm DPP moves: one Philox block
+// per 16 probabilities and lane instead of one per 4 (the generator was ~25 VALU instructions per probability — more than the
+// softmax itself; attention dropout cost 4 ms of a 70 ms step).  The mask is the same function of (b, h, q, k) as before.
+#define VAC_QUAD_BCAST(V_, G_) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(V_), (G_) * 0x55, 0xf, 0xf, true))
+// forward / dQ: this lane's query q (q & 3 == lane & 3), 32-key block starting at kblock (+ 4 * lane half): mw[g] = mask word of
+// keys kblock + 8 g .. + 3
+__device__ __forceinline__ void drop_block_keys(const DropCtx& d, int q, int kblock, int lane, uint32_t mw[4]) {
+  const int i = lane & 3;
   uint32_t w[4];
-  drop_patch(d, q, k0, w);
-  const uint32_t x = w[q & 3];
+  drop_patch(d, q, kblock + 8 * i, w);
+#define VAC_TAKE(G_)                                                                                   \
+  {                                                                                                    \
+    const uint32_t t0 = VAC_QUAD_BCAST(w[0], G_), t1 = VAC_QUAD_BCAST(w[1], G_);                       \
+    const uint32_t t2 = VAC_QUAD_BCAST(w[2], G_), t3 = VAC_QUAD_BCAST(w[3], G_);                       \
+    mw[G_] = i == 0 ? t0 : i == 1 ? t1 : i == 2 ? t2 : t3;                                             \
+  }
+  VAC_TAKE(0) VAC_TAKE(1) VAC_TAKE(2) VAC_TAKE(3)
+#undef VAC_TAKE
+}
+__device__ __forceinline__ void drop_word_factors(const DropCtx& d, uint32_t x, float m[4]) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) m[e] = ((x >> (8 * e)) & 0xffu) >= d.thr ? d.inv : 0.f;
 }
-// keep factors of the 4 queries q0 .. q0+3 (q0 % 4 == 0) for key k
-__device__ __forceinline__ void drop_queries4(const DropCtx& d, int q0, int k, float m[4]) {
+// dK/dV: this lane's key k (k & 3 == lane & 3), 32-query block starting at qblock (+ 4 * lane half): mb[g] = the mask bytes of
+// queries qblock + 8 g .. + 3 for key k, packed like a mask word
+__device__ __forceinline__ void drop_block_queries(const DropCtx& d, int qblock, int k, int lane, uint32_t mb[4]) {
+  const int i = lane & 3, sh = 8 * i;
   uint32_t w[4];
-  drop_patch(d, q0, k, w);
-  const int sh = 8 * (k & 3);
-#pragma unroll
-  for (int e = 0; e < 4; ++e) m[e] = ((w[e] >> sh) & 0xffu) >= d.thr ? d.inv : 0.f;
+  drop_patch(d, qblock + 8 * i, k, w);
+#define VAC_TAKE(G_)                                                                                   \
+  {                                                                                                    \
+    const uint32_t t0 = VAC_QUAD_BCAST(w[0], G_), t1 = VAC_QUAD_BCAST(w[1], G_);                       \
+    const uint32_t t2 = VAC_QUAD_BCAST(w[2], G_), t3 = VAC_QUAD_BCAST(w[3], G_);                       \
+    mb[G_] = ((t0 >> sh) & 0xffu) | (((t1 >> sh) & 0xffu) << 8) | (((t2 >> sh) & 0xffu) << 16) | (((t3 >> sh) & 0xffu) << 24); \
+  }
+  VAC_TAKE(0) VAC_TAKE(1) VAC_TAKE(2) VAC_TAKE(3)
+#undef VAC_TAKE
 }
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const bf16_t* base, int rows, int ld) {
@@ -256,14 +280,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
     m_run = m_new;
     if (DROP) {          // the normaliser sums the undropped probabilities (softmax first, dropout second: MFULL:534,546)
 #pragma unroll
-      for (int kb2 = 0; kb2 < 2; ++kb2)
+      for (int kb2 = 0; kb2 < 2; ++kb2) {
+        uint32_t mw[4];
+        drop_block_keys(dctx, qidx, t * 64 + kb2 * 32 + 4 * hh, lane, mw);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           float mk[4];
-          drop_keys4(dctx, qidx, t * 64 + kb2 * 32 + 8 * g + 4 * hh, mk);
+          drop_word_factors(dctx, mw[g], mk);
 #pragma unroll
           for (int e = 0; e < 4; ++e) s[kb2][4 * g + e] *= mk[e];
         }
+      }
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
@@ -425,13 +452,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnP p) {
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(qt, qb2 * 32, ks4, lane), kf[ks4], s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(dot, qb2 * 32, ks4, lane), vf[ks4], dp, 0, 0, 0);
       }
+      uint32_t mb[4];
+      if (DROP) drop_block_queries(dctx, t * 64 + qb2 * 32 + 4 * hh, kidx, lane, mb);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int ql0 = qb2 * 32 + 8 * g + 4 * hh;
         const f32x4 l4 = *(const f32x4*)(st + ql0);
         const f32x4 d4 = *(const f32x4*)(st + 64 + ql0);
         float mq[4] = {1.f, 1.f, 1.f, 1.f};
-        if (DROP) drop_queries4(dctx, t * 64 + ql0, kidx, mq);
+        if (DROP) drop_word_factors(dctx, mb[g], mq);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float v = s[4 * g + e] * p.scale + kbias;
@@ -546,12 +575,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(kt, kb2 * 32, ks4, lane), qf[ks4], s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(vt, kb2 * 32, ks4, lane), dof[ks4], dp, 0, 0, 0);
       }
+      uint32_t mw[4];
+      if (DROP) drop_block_keys(dctx, qidx, t * 64 + kb2 * 32 + 4 * hh, lane, mw);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int kbase = t * 64 + kb2 * 32 + 8 * g + 4 * hh;
         const f32x4 bias = *(const f32x4*)(kbias + kbase);
         float mk[4] = {1.f, 1.f, 1.f, 1.f};
-        if (DROP) drop_keys4(dctx, qidx, kbase, mk);
+        if (DROP) drop_word_factors(dctx, mw[g], mk);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float v = s[4 * g + e] * p.scale + bias[e];

@@ -161,6 +161,36 @@ __device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2
 __device__ __forceinline__ void dropout_bits4(uint64_t seed, uint64_t idx4, uint32_t out[4]) {
   philox4x32((uint32_t)idx4, (uint32_t)(idx4 >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), out);
 }
+// ---- activation dropout (hidden states of the FFN blocks, MFULL:649,660,684,740,874) ------------------------------------------
+// Element e of a flat contiguous array takes byte e & 15 of Philox block e >> 4 (16 keep decisions per block); keep iff
+// byte >= thr, p quantised to 1/256 like the attention-probability dropout.  The GEMM epilogues (forward: after the activation;
+// backward: after act') and vacnic_dropout_bf16 evaluate the same function, so nothing is stored.
+__device__ __forceinline__ void actdrop_block(uint64_t seed, uint64_t blk, uint32_t w[4]) {
+  philox4x32((uint32_t)blk, (uint32_t)(blk >> 32), 0x41435444u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+}
+__device__ __forceinline__ void actdrop_factors8(uint32_t lo, uint32_t hi, unsigned thr, float inv, float m[8]) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    m[e] = ((lo >> (8 * e)) & 0xffu) >= thr ? inv : 0.f;
+    m[4 + e] = ((hi >> (8 * e)) & 0xffu) >= thr ? inv : 0.f;
+  }
+}
+// Two adjacent lanes own the two 8-element halves of the same 16-element blocks, row by row: for a PAIR of rows the even lane
+// generates the first row's block and the odd lane the second's, and each hands the partner its half with two quad_perm DPP
+// moves — one Philox block per 16 decisions and lane.  blk_a / blk_b: block index of the first / second row (this lane's column
+// group); returns the mask words {lo, hi} of this lane's 8 elements in both rows.  All lanes of a pair must call it together.
+__device__ __forceinline__ void actdrop_pair(uint64_t seed, uint64_t blk_a, uint64_t blk_b, int lane, uint32_t& a_lo, uint32_t& a_hi,
+                                             uint32_t& b_lo, uint32_t& b_hi) {
+  const bool odd = (lane & 1) != 0;
+  uint32_t w[4];
+  actdrop_block(seed, odd ? blk_b : blk_a, w);
+  const uint32_t s0 = odd ? w[0] : w[2], s1 = odd ? w[1] : w[3];          // the half the partner owns
+  const uint32_t r0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s0, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+  const uint32_t r1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s1, 0xB1, 0xf, 0xf, true);
+  a_lo = odd ? r0 : w[0]; a_hi = odd ? r1 : w[1];
+  b_lo = odd ? w[2] : r0; b_hi = odd ? w[3] : r1;
+}
+
 __device__ __forceinline__ uint32_t dropout_threshold(float p) {
   // keep iff bits >= thr  (P(keep) = 1-p)
   double t = (double)p * 4294967296.0;

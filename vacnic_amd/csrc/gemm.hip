@@ -401,6 +401,17 @@ static int gemm_one(const vacnic_gemm_args* a, int tile_hint, void* stream, int 
   p.tiles_m = p.tiles_n = 0;
   p.ws = (a->workspace && zsplits > 1) ? (float*)a->workspace : nullptr;
   p.cnt = p.ws ? a->counters : nullptr;
+  p.drop_thr = 0; p.drop_inv = 1.f; p.drop_seed = a->drop_seed; p.drop_seed_dev = (const unsigned long long*)a->drop_seed_dev;
+  if (a->drop_p != 0.f) {
+    VCHECK(a->drop_p > 0.f && a->drop_p < 1.f, VACNIC_BAD_SHAPE, "gemm: drop_p must be in [0, 1)");
+    VCHECK(a->out_mode == 0 && a->ldo == a->N && (a->N & 15) == 0 && !ce_mode && tile_hint != 8, VACNIC_UNSUPPORTED,
+           "gemm: fused activation dropout needs a contiguous bf16 output with N %% 16 == 0 (use vacnic_dropout_bf16)");
+    VCHECK((zsplits == 1 || p.ws) , VACNIC_UNSUPPORTED, "gemm: fused activation dropout with split-K needs the fix-up workspace");
+    unsigned thr = (unsigned)(a->drop_p * 256.f + 0.5f);
+    if (thr > 255) thr = 255;
+    p.drop_thr = thr;                                  // (p < 1/512 rounds to "off")
+    p.drop_inv = 256.f / (256.f - (float)thr);
+  }
   hipStream_t s = (hipStream_t)stream;
   if (tile_hint == 8) {     // skinny-M kernel (chosen by vacnic_gemm_bf16 for M <= 8, or forced by the caller)
     VCHECK(a->M <= 8 && !a->x_kstrided && !a->w_kstrided && zsplits == 1 && !a->preact && !a->dact_src && !a->residual && !a->xsum &&
@@ -424,8 +435,14 @@ static int gemm_one(const vacnic_gemm_args* a, int tile_hint, void* stream, int 
   // the bf16 epilogue addresses its outputs through 32-bit buffer offsets: larger outputs take the fp32-staged path
   if (((a->M - 1) * a->ldo + a->N) * 2 >= 0x7ffffff0LL) p.debug |= 16;
   if ((a->preact != nullptr) + (a->dact_src != nullptr) + (a->residual != nullptr) > 1) p.debug |= 16;   // bf16 epilogue: one extra operand
+  if (p.drop_thr && !a->preact && !a->dact_src) p.debug |= 16;     // dropout rides on the saved-pre-activation / act' instances of the bf16 epilogue
   const bool big = force == 256;
   const bool mid = force == 128;
+  if (p.drop_thr) {                 // activation dropout: 256 x 256, 256 x 128 and 64 x 128 tiles carry the DR epilogues
+    if (big) return launch_t256d(p, a->x_kstrided, a->w_kstrided, zsplits, s);
+    if (force == 264) return launch_t264d(p, a->x_kstrided, a->w_kstrided, zsplits, s);
+    return launch_t64d(p, a->x_kstrided, a->w_kstrided, zsplits, s);
+  }
   // A/B baselines kept for the ablations in profiles/: plain K loops and the 64-wide software-pipelined loop
   if (force == 260) return launch_t260(p, a->x_kstrided, a->w_kstrided, zsplits, s);
   if (force == 261) return launch_t261(p, a->x_kstrided, a->w_kstrided, zsplits, s);

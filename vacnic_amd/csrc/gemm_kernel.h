@@ -22,6 +22,9 @@ struct GemmP {
   unsigned x_bytes, w_bytes;
   int tiles_m, tiles_n;
   int ce_col0;          // out_mode 3 / 4: global vocabulary index of this launch's column 0 (targets are global ids)
+  // activation dropout fused into the epilogue (after the activation / after act'): common.h "activation dropout"; thr 0 = off.
+  // The output must be a contiguous [M, N] bf16 array with N % 16 == 0 (element index m * N + n).
+  unsigned drop_thr; float drop_inv; unsigned long long drop_seed; const unsigned long long* drop_seed_dev;
   float* ws;            // split-K with ordered fix-up (see gemm_tile): fp32 partial tiles [tile][split][BM*BN]; nullptr = atomics
   unsigned* cnt;        // one arrival counter per output tile (zero before the launch, zero again after it)
   int debug;            // profiling aid (tile_hint >= 1000): bit0 skip the global stores, bit1 skip the K loop, bit2 skip the epilogue, bit3 return at once, bit4 fp32 staged epilogue, bit5 no LDS-DMA in the loop, bit7 no fragment reads
@@ -116,7 +119,9 @@ __device__ __forceinline__ void unpack8bf(u32x4 r, float v[8]) {
 
 // 8 consecutive, fully in-range, 16-byte-aligned outputs of one row.  Bias and the raw residual / activation-source words
 // were loaded by the caller (batched over all of a thread's chunks, so their latency overlaps).
-__device__ __forceinline__ void epilogue8_vec(const GemmP& p, float v[8], size_t off, const float bia[8], u32x4 rraw, u32x4 draw) {
+template <bool DR = false>
+__device__ __forceinline__ void epilogue8_vec(const GemmP& p, float v[8], size_t off, const float bia[8], u32x4 rraw, u32x4 draw,
+                                              uint32_t mlo = 0, uint32_t mhi = 0) {
   if (p.alpha != 1.0f) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] *= p.alpha;
@@ -132,6 +137,12 @@ __device__ __forceinline__ void epilogue8_vec(const GemmP& p, float v[8], size_t
   } else if (p.act != VACNIC_ACT_NONE) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = act_fwd(p.act, v[j]);
+  }
+  if constexpr (DR) {
+    float m[8];
+    actdrop_factors8(mlo, mhi, p.drop_thr, p.drop_inv, m);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= m[j];
   }
   if (p.residual) {
     float d[8];
@@ -236,11 +247,14 @@ __device__ __forceinline__ void lds_barrier() {
 template <int N>
 __device__ __forceinline__ void wait_vm_lgkm() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
 
+// DR: compile the activation-dropout epilogues (GemmP::drop_*) — their own instantiations (gemm_t*d.hip) for the same reason as CE:
+// inside the general kernels the extra epilogue code cost the 128 x 128 tile 18 VGPRs (occupancy 3 -> 2) and the 256 x 256 tile
+// scratch.  A DR kernel always applies dropout (the host launches it only with drop_thr != 0).
 // CE: compile the fused LM-head cross-entropy epilogues (out_mode 3 / 4) — their own instantiation (gemm_t256ce.hip): inside the
 // general kernels their code raised the register allocation of EVERY epilogue path (128x128 tiles: 181 -> 256 VGPRs + scratch).
 // One output tile: rows [m0, m0 + BM) x columns [n0, n0 + BN), reduction slice `zsplit`.  `tn` = this tile's column index inside
 // its row panel and p.tiles_n the number of tiles that share the panel (the xsum K-steps are dealt round-robin over them).
-template <int BM, int BN, int WM, int WN, int BKT, int NSTAGE, bool PIPE, bool XKS, bool WKS, bool CE>
+template <int BM, int BN, int WM, int WN, int BKT, int NSTAGE, bool PIPE, bool XKS, bool WKS, bool CE, bool DR = false>
 __device__ __forceinline__ void gemm_tile(const GemmP& p, const int m0, const int n0, const int tn, const int zsplit, const int tile_id = 0) {
   constexpr int NWAVE = WM * WN, NTHR = 64 * NWAVE;
   constexpr int TM = BM / WM, TN = BN / WN;             // per-wave output sub-tile
@@ -514,7 +528,7 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, const int m0, const in
   // ---- direct epilogue for the common plain case (bf16 out, bias + activation only): each lane owns 4 consecutive n of
   // one m per accumulator tile -> bias as one 16-byte load, pack with v_cvt_pk_bf16_f32, one 8-byte store.  No LDS
   // round trip, no barriers; the 32-byte row pieces of the four n-groups are merged by the L2.
-  if (BM <= 128 && p.out_mode == 0 && !p.preact && !p.dact_src && !p.residual && (p.ldo & 3) == 0 && !(p.debug & 16)) {
+  if (BM <= 128 && p.out_mode == 0 && !p.preact && !p.dact_src && !p.residual && (p.ldo & 3) == 0 && !(p.debug & 16) && !DR) {
     const int lm_ = lane & 15, ln4_ = (lane >> 4) * 4;
     const bool add_bias_ = p.bias != nullptr;
 #pragma unroll
@@ -616,6 +630,14 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, const int m0, const in
       const unsigned vstep = (n + 8 <= p.N && !(p.debug & 1)) ? rstride : 0u;
       __amdgpu_buffer_rsrc_t so = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, span, 0x00020000);
       const bool plain = !p.preact && !p.dact_src && !p.residual;
+      // activation dropout (host: contiguous output, N % 16 == 0, never on the plain path): Philox block of this thread's column
+      // group in row m0 + rb, and the block stride between two of its rows
+      unsigned long long dseed = 0, dblk_step = 0, dblk0 = 0;
+      if constexpr (DR) {
+        dseed = p.drop_seed_dev ? p.drop_seed ^ (*p.drop_seed_dev * 0x9E3779B97F4A7C15ull) : p.drop_seed;
+        dblk_step = (unsigned long long)RSTEP * (unsigned)(p.N >> 4);
+        dblk0 = (unsigned long long)(m0 + rb) * (unsigned)(p.N >> 4) + (unsigned)(n >> 4);
+      }
       // exactly one of residual / preact / dact_src may ride on this path (the host sends combinations to the fp32 path);
       // each gets its own straight-line instance: MODE 1 residual, 2 saved pre-activation (+ activation), 3 activation backward
       auto tail = [&](auto mode_c, auto act_c) {
@@ -625,6 +647,7 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, const int m0, const in
 #pragma unroll
         for (int k0 = 0; k0 < NIT; k0 += 8) {
           u32x4 ex[8];
+          uint32_t mlo[8], mhi[8];
           __builtin_amdgcn_sched_barrier(0);          // one batch of 8 rows at a time (the C tile already holds 64 registers)
           if (MODE != 2) {
 #pragma unroll
@@ -633,6 +656,12 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, const int m0, const in
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
             float v[8], d[8];
+            if constexpr (DR && MODE != 1) {            // activation dropout: masks of a row pair from one Philox block per lane
+              if ((k & 1) == 0) {
+                const unsigned long long ba = dblk0 + (unsigned long long)(k0 + k) * dblk_step;
+                actdrop_pair(dseed, ba, ba + dblk_step, lane, mlo[k], mhi[k], mlo[k + 1], mhi[k + 1]);
+              }
+            }
             unpack8bf(cv[k0 + k], v);
             if (MODE == 2) {
               __builtin_amdgcn_raw_buffer_store_b128(cv[k0 + k], se, voff + (k0 + k) * vstep, 0, 0);
@@ -642,6 +671,12 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, const int m0, const in
               unpack8bf(ex[k], d);
 #pragma unroll
               for (int j = 0; j < 8; ++j) v[j] = MODE == 1 ? v[j] + d[j] : v[j] * act_bwd(ACT, d[j]);
+            }
+            if constexpr (DR && MODE != 1) {
+              float m[8];
+              actdrop_factors8(mlo[k], mhi[k], p.drop_thr, p.drop_inv, m);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] *= m[j];
             }
             const u32x4 o = (u32x4){pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
             __builtin_amdgcn_raw_buffer_store_b128(o, so, voff + (k0 + k) * vstep, 0, 0);
@@ -810,6 +845,20 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, const int m0, const in
       }
       float v[RPT][8];
       u32x4 rraw[RPT], draw[RPT];
+      uint32_t mlo[RPT], mhi[RPT];
+      if constexpr (DR) {                               // activation dropout masks of this thread's rows (one Philox block per row pair)
+        static_assert(RPT % 2 == 0, "row pairs");
+        const unsigned long long dseed = p.drop_seed_dev ? p.drop_seed ^ (*p.drop_seed_dev * 0x9E3779B97F4A7C15ull) : p.drop_seed;
+#pragma unroll
+        for (int k = 0; k < RPT; k += 2) {
+          const unsigned long long ba = (unsigned long long)(m0 + tile_row(pass, rbase + k * RSTEP)) * (unsigned)(p.N >> 4) + (unsigned)(n >> 4);
+          const unsigned long long bb = (unsigned long long)(m0 + tile_row(pass, rbase + (k + 1) * RSTEP)) * (unsigned)(p.N >> 4) + (unsigned)(n >> 4);
+          actdrop_pair(dseed, ba, bb, lane, mlo[k], mhi[k], mlo[k + 1], mhi[k + 1]);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) { mlo[k] = 0; mhi[k] = 0; }
+      }
 #pragma unroll
       for (int k = 0; k < RPT; ++k) {
         const int row = rbase + k * RSTEP;
@@ -827,7 +876,7 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, const int m0, const in
 #pragma unroll
       for (int k = 0; k < RPT; ++k) {
         const int m = m0 + tile_row(pass, rbase + k * RSTEP);
-        if (m < p.M) epilogue8_vec(p, v[k], (size_t)m * p.ldo + n, bia, rraw[k], draw[k]);
+        if (m < p.M) epilogue8_vec<DR>(p, v[k], (size_t)m * p.ldo + n, bia, rraw[k], draw[k], mlo[k], mhi[k]);
       }
     } else if (n < p.N) {
 #pragma unroll 1
@@ -848,7 +897,7 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, const int m0, const in
 }
 
 
-template <int BM, int BN, int WM, int WN, int BKT, int NSTAGE, bool PIPE, bool XKS, bool WKS, bool CE = false>
+template <int BM, int BN, int WM, int WN, int BKT, int NSTAGE, bool PIPE, bool XKS, bool WKS, bool CE = false, bool DR = false>
 __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
   if (p.debug & 8) return;
   // XCD-aware work order.  Workgroup L of the 1-D grid runs on XCD L % 8, each with its own 4 MiB L2.
@@ -868,7 +917,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmP p) {
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
   const int tm = bid / p.tiles_n, tn = bid - tm * p.tiles_n;
-  gemm_tile<BM, BN, WM, WN, BKT, NSTAGE, PIPE, XKS, WKS, CE>(p, tm * BM, tn * BN, tn, zsplit, bid);
+  gemm_tile<BM, BN, WM, WN, BKT, NSTAGE, PIPE, XKS, WKS, CE, DR>(p, tm * BM, tn * BN, tn, zsplit, bid);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -911,7 +960,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_group_kernel(GroupP g) {
   p.act = VACNIC_ACT_NONE; p.out_mode = 2; p.split_k = 1; p.k_per_split = g.k_per_phase;
   p.alpha = 1.0f; p.x_bytes = u.x_bytes; p.w_bytes = u.w_bytes;
   p.tiles_m = GROUP_UT; p.tiles_n = min(GROUP_UT, (u.N - u.un0 + BN - 1) / BN);
-  p.ce_col0 = 0; p.debug = g.debug; p.ws = nullptr; p.cnt = nullptr;
+  p.ce_col0 = 0; p.debug = g.debug; p.ws = nullptr; p.cnt = nullptr; p.drop_thr = 0;
   gemm_tile<BM, BN, WM, WN, BKT, NSTAGE, PIPE, true, true, false>(p, m0, n0, tn, g.kphase);
 }
 
@@ -932,7 +981,7 @@ int launch_gemm_group(const GroupP& g, hipStream_t s) {
 }
 
 
-template <int BM, int BN, int WM, int WN, int BKT, int NSTAGE, bool PIPE = false, bool CE = false>
+template <int BM, int BN, int WM, int WN, int BKT, int NSTAGE, bool PIPE = false, bool CE = false, bool DR = false>
 int launch_gemm(const GemmP& p0, bool xks, bool wks, int zsplits, hipStream_t s) {
   GemmP p = p0;
   p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
@@ -942,7 +991,7 @@ int launch_gemm(const GemmP& p0, bool xks, bool wks, int zsplits, hipStream_t s)
   static_assert(lds >= 64 * (BN + 4) * 4, "epilogue staging must fit in the operand buffers");
 #define VAC_LAUNCH(XK, WK)                                                                            \
   do {                                                                                                \
-    auto kern = gemm_kernel<BM, BN, WM, WN, BKT, NSTAGE, PIPE, XK, WK, CE>;                                              \
+    auto kern = gemm_kernel<BM, BN, WM, WN, BKT, NSTAGE, PIPE, XK, WK, CE, DR>;                                          \
     if (lds > 65536) {                                                                                \
       static bool once = false;                                                                       \
       if (!once) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; } \
@@ -952,6 +1001,9 @@ int launch_gemm(const GemmP& p0, bool xks, bool wks, int zsplits, hipStream_t s)
   if constexpr (CE) {
     if (xks || wks) { vacnic_set_error("gemm: the cross-entropy epilogues are built for the forward layout only"); return VACNIC_UNSUPPORTED; }
     VAC_LAUNCH(false, false);
+  } else if constexpr (DR) {         // activation dropout: the forward Linear and the dgrad that carries act' (K-contiguous X)
+    if (xks) { vacnic_set_error("gemm: fused activation dropout is built for K-contiguous X (forward / dgrad layouts)"); return VACNIC_UNSUPPORTED; }
+    if (wks) VAC_LAUNCH(false, true); else VAC_LAUNCH(false, false);
   } else {
     if (!xks && !wks) VAC_LAUNCH(false, false);
     else if (!xks && wks) VAC_LAUNCH(false, true);
@@ -973,6 +1025,9 @@ int launch_t260(const GemmP& p, bool xks, bool wks, int zsplits, hipStream_t s);
 int launch_t261(const GemmP& p, bool xks, bool wks, int zsplits, hipStream_t s);
 int launch_t262(const GemmP& p, bool xks, bool wks, int zsplits, hipStream_t s);
 int launch_t256ce(const GemmP& p, bool xks, bool wks, int zsplits, hipStream_t s); // 256x256 ping-pong + LM-head cross-entropy epilogues
+int launch_t256d(const GemmP& p, bool xks, bool wks, int zsplits, hipStream_t s);  // the same tiles with the activation-dropout epilogues (DR)
+int launch_t264d(const GemmP& p, bool xks, bool wks, int zsplits, hipStream_t s);
+int launch_t64d(const GemmP& p, bool xks, bool wks, int zsplits, hipStream_t s);
 int launch_group128(const GroupP& g, hipStream_t s);                                // grouped weight gradients, 128x128 tiles (gemm_tgroup.hip)
 
 }  // namespace vacgemm

@@ -474,19 +474,26 @@ static int check_d(int64_t D, const char* who) {
 // activation dropout of the FFN blocks (MFULL:649,660,684,740,874): forward on act(fc1 x), backward on the gradient of the same
 // elements with the same (seed, element index) -> the same mask, nothing stored.
 namespace {
-__global__ __launch_bounds__(256) void dropout_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int64_t nchunk, float p_drop,
-                                                      uint64_t seed, const uint64_t* __restrict__ seed_dev) {
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= nchunk) return;
+__global__ __launch_bounds__(256) void dropout_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int64_t nchunk, unsigned thr,
+                                                      float inv_keep, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+  // one thread per 16-element Philox block (two 8-element chunks; the last block of an array with n % 16 == 8 has one)
+  const int64_t blk = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (2 * blk >= nchunk) return;
   seed = mix_seed(seed, seed_dev);
-  const uint32_t thr = dropout_threshold(p_drop);
-  const float inv_keep = 1.f / (1.f - p_drop);
-  float v[8], m[8];
-  load8(x + c * 8, v);
-  drop8(seed, (uint64_t)c * 8, thr, inv_keep, m);
+  uint32_t w[4];
+  actdrop_block(seed, (uint64_t)blk, w);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] *= m[j];
-  store8(out + c * 8, v);
+  for (int h = 0; h < 2; ++h) {
+    const int64_t c = 2 * blk + h;
+    if (c < nchunk) {
+      float v[8], m[8];
+      load8(x + c * 8, v);
+      actdrop_factors8(w[2 * h], w[2 * h + 1], thr, inv_keep, m);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] *= m[j];
+      store8(out + c * 8, v);
+    }
+  }
 }
 }  // namespace
 
@@ -497,8 +504,11 @@ extern "C" int vacnic_dropout_bf16(const void* x, void* out, int64_t n, float p_
   VCHECK(p_drop > 0.f && p_drop < 1.f, VACNIC_BAD_SHAPE, "dropout: 0 < p < 1");
   if (n == 0) return VACNIC_OK;
   const int64_t nchunk = n >> 3;
-  hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((nchunk + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)out,
-                     nchunk, p_drop, seed, seed_dev);
+  unsigned thr = (unsigned)(p_drop * 256.f + 0.5f);        // p quantised to 1/256, as in the GEMM epilogues that apply the same mask
+  if (thr > 255) thr = 255;
+  const int64_t nblk = (nchunk + 1) / 2;
+  hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)out,
+                     nchunk, thr, 256.f / (256.f - (float)thr), seed, seed_dev);
   VLAUNCH_CHECK();
   return VACNIC_OK;
 }

@@ -132,10 +132,12 @@ def _fix_buffers(stream, M, N, split_k):
 
 
 def gemm(x, w, M, N, K, *, bias=None, out=None, ldx=None, ldw=None, ldo=None, x_kstrided=False, w_kstrided=False,
-         act=None, out_mode=0, split_k=1, alpha=1.0, preact=None, dact_src=None, residual=None, tile_hint=0, xsum=None, fixup=False):
+         act=None, out_mode=0, split_k=1, alpha=1.0, preact=None, dact_src=None, residual=None, tile_hint=0, xsum=None, fixup=False,
+         drop=None):
     """out[m][n] = epi(alpha * sum_k X(m,k) W(n,k) + bias[n]) — see include/vacnic_hip.h.
     tile_hint 0: measured winner for this exact shape if gemm_tuned.json has one, else the C-side cost model; -1: cost model.
-    fixup: split_k > 1 through the ordered fix-up (no atomics, bitwise reproducible, any out_mode) instead of fp32 atomics."""
+    fixup: split_k > 1 through the ordered fix-up (no atomics, bitwise reproducible, any out_mode) instead of fp32 atomics.
+    drop: (p, seed, seed_dev tensor or None) — activation dropout in the epilogue (after act / act'); see can_fuse_dropout."""
     if out is None:
         out = torch.empty((M, N), device=x.device, dtype=BF16 if out_mode == 0 else torch.float32)
     ldx = ldx if ldx is not None else (M if x_kstrided else K)
@@ -161,8 +163,14 @@ def gemm(x, w, M, N, K, *, bias=None, out=None, ldx=None, ldw=None, ldo=None, x_
                 dact_src=_p(dact_src), residual=_p(residual), xsum=_p(xsum), M=M, N=N, K=K, ldx=ldx, ldw=ldw, ldo=ldo,
                 x_kstrided=int(x_kstrided), w_kstrided=int(w_kstrided), act=ACT[act], out_mode=out_mode,
                 split_k=split_k, alpha=alpha, tile_hint=tile_hint, workspace=ws, workspace_bytes=wsb or 0, counters=cnt,
-                counters_len=cntn or 0)
+                counters_len=cntn or 0, drop_p=float(drop[0]) if drop else 0.0, drop_seed=int(drop[1]) if drop else 0,
+                drop_seed_dev=_p(drop[2]) if drop else None)
     return out
+
+
+def can_fuse_dropout(N, ldo=None):
+    """the GEMM epilogue can apply activation dropout to a contiguous [M, N] bf16 output with N % 16 == 0."""
+    return N % 16 == 0 and (ldo is None or ldo == N)
 
 
 def gemv_ln(x, residual, gamma, beta, w, M, N, Kd, *, bias=None, out=None, ln_out=None, ldw=None, ldo=None, act=None, out_mode=0, eps=1e-5):

@@ -20,6 +20,7 @@ from . import streams
 
 BF16 = torch.bfloat16
 _NO_XSUM = __import__("os").environ.get("VACNIC_NO_XSUM") == "1"
+_FUSE_ACT_DROPOUT = __import__("os").environ.get("VACNIC_FUSE_ACT_DROPOUT", "1") != "0"      # A/B: 0 = separate in-place dropout passes
 
 
 class Rng:
@@ -350,8 +351,11 @@ class Mlp2Fn(Function):
         need = ge and any(ctx.needs_input_grad)      # grad mode is always off inside Function.forward: `ge` comes from the caller
         u = torch.empty((M, s1.N), device=x.device, dtype=BF16) if need else None
         h = torch.empty((M, s1.N), device=x.device, dtype=BF16)
-        K.gemm(x2, s1.w16, M, s1.N, s1.K, bias=s1.bias, out=h, ldw=s1.ldw, act=act, preact=u)
-        if p_act > 0.0:
+        # activation dropout rides in the epilogue (after the activation); widths that are not multiples of 16: a separate pass
+        fuse = p_act > 0.0 and K.can_fuse_dropout(s1.N) and _FUSE_ACT_DROPOUT
+        K.gemm(x2, s1.w16, M, s1.N, s1.K, bias=s1.bias, out=h, ldw=s1.ldw, act=act, preact=u,
+               drop=(p_act, seed, Rng.device_counter()) if fuse else None)
+        if p_act > 0.0 and not fuse:
             K.dropout_(h, p_act, seed, Rng.device_counter())
         out = torch.empty(x.shape[:-1] + (s2.N,), device=x.device, dtype=BF16)
         K.gemm(h, s2.w16, M, s2.N, s2.K, bias=s2.bias, out=out, ldw=s2.ldw)
@@ -374,8 +378,10 @@ class Mlp2Fn(Function):
         if s2.N % 8:                                   # 20-wide name-prefix output: give the GEMMs 16-byte rows
             dy2 = K.pad_cols(dy2, (s2.N + 7) // 8 * 8)
         du = torch.empty((M, s1.N), device=dy.device, dtype=BF16)
-        K.gemm(dy2, s2.w16, M, s1.N, s2.N, out=du, ldx=dy2.stride(0), ldw=s2.ldw, w_kstrided=True, act=act, dact_src=u)
-        if ctx.p_act > 0.0:                            # the mask commutes with the elementwise act'(u) the epilogue applied
+        fuse = ctx.p_act > 0.0 and K.can_fuse_dropout(s1.N) and _FUSE_ACT_DROPOUT
+        K.gemm(dy2, s2.w16, M, s1.N, s2.N, out=du, ldx=dy2.stride(0), ldw=s2.ldw, w_kstrided=True, act=act, dact_src=u,
+               drop=(ctx.p_act, ctx.seed, Rng.device_counter()) if fuse else None)
+        if ctx.p_act > 0.0 and not fuse:               # the mask commutes with the elementwise act'(u) the epilogue applied
             K.dropout_(du, ctx.p_act, ctx.seed, Rng.device_counter())
         _wgrad(dy2, h, s2, M)                          # h is the DROPPED activation: what fc2 saw in forward
         dx = None
