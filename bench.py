@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="replay the step as one captured hipGraph (world 1 only). Measured slower than "
                     "eager multi-stream launches while the step is GPU-bound (91.0 vs 86.2 ms: hipGraph runs the side-stream branches "
                     "less concurrently), so eager is the default")
-    ap.add_argument("--no-plan", action="store_true", help="world 1: issue every step from Python (eager) instead of replaying the recorded launch "
+    ap.add_argument("--no-plan", action="store_true", help="issue every step from Python (eager) instead of replaying the recorded launch "
                     "plan (vacnic_plan_replay: the same multi-stream schedule re-issued from C++, a handful of C-ABI calls per step). "
                     "Same-box A/B: 68.4 vs 68.6 ms per step; launch path 7 vs 24 ms of host time per step")
     ap.add_argument("--mock-step", action="store_true", help=argparse.SUPPRESS)    # tests/test_bench_launch.py: launcher plumbing without a GPU
@@ -504,7 +504,7 @@ def main():
             torch.cuda.synchronize()
     planned = None
     host_idle_gpu = None
-    if world == 1 and not a.no_plan and graphed is None:
+    if not a.no_plan and graphed is None:          # N > 1 too: every rank replays its plan, the reducer's collectives are host actions at its marks
         try:
             planned = PlannedTrainStep(net, guide, opt, args, batches[0], warmup=max(1, a.warmup - 1), towers=towers)
             t_h = time.perf_counter()

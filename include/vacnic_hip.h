@@ -477,11 +477,16 @@ int vacnic_zero_bytes(void* ptr, int64_t bytes, void* stream);
  * while it runs; vacnic_plan_replay(h, first, last) re-issues commands [first, last) — same kernels, same streams, same order.
  * The caller keeps all buffers at their recorded addresses and refreshes inputs in place.  vacnic_plan_mark() (while recording)
  * = index of the next command, for replays split around host-side work.  vacnic_stream_fence(src, dst): dst waits for all work
- * enqueued on src so far — the recordable form of an event record + stream wait.  Handles are small integers; -1 = error. */
+ * enqueued on src so far — the recordable form of an event record + stream wait.  vacnic_plan_pause(1) .. vacnic_plan_pause(0)
+ * (recording thread only; nests): calls in between run but are NOT recorded — the work the host repeats itself at a mark of
+ * every replay (the DDP reducer's bucket casts and RCCL launches, reference role TRAIN:87).  Recording is bound to the thread
+ * that called vacnic_plan_begin, and an entry point that returns an error while recording leaves no command behind.
+ * Handles are small integers; -1 = error. */
 int64_t vacnic_plan_begin(void);
 int vacnic_plan_end(int64_t plan);
 int64_t vacnic_plan_size(int64_t plan);
 int64_t vacnic_plan_mark(void);
+int vacnic_plan_pause(int on);
 int vacnic_plan_replay(int64_t plan, int64_t first, int64_t last);
 int vacnic_plan_destroy(int64_t plan);
 int vacnic_stream_fence(void* src_stream, void* dst_stream);

@@ -97,6 +97,54 @@ def _worker(rank, world, port, q):
         fo = FakeOpt()
         w.reduce_and_step(fo, clip_norm=0.1)                # clipping needs the global norm: plain reduce, one step
         assert fo.calls == [("full", 0.1)] and torch.allclose(m.arena.grad, torch.full_like(m.arena.grad, 3.0))
+        # launch plans at world > 1 (training.PlannedTrainStep): while a step is RECORDED the reducer's host-side work goes through
+        # ddp.HOST_HOOK — each piece runs at once and is kept as a host action at its position between the recorded commands
+        # (here: the optimizer's range updates); a REPLAY re-runs the host actions and the commands in that order, with no
+        # tracker activity at all.  The replay must reduce a fresh set of gradients exactly like an eager step does.
+        plan = []
+
+        class PlanOpt:                                      # stands for the C-ABI calls a plan records (AdamW per bucket range)
+            def begin_step(self):
+                plan.append(("cmd", "begin"))
+
+            def step_range(self, a, b):
+                plan.append(("cmd", (a, b)))
+
+        ddp.HOST_HOOK = lambda fn: (plan.append(("host", fn)), fn())
+        ddp.TRACKER = tr                                    # (the bf16-transport wrapper above installed its own)
+        m.arena.grad.fill_(float(rank + 1))                 # (alignment gaps between the parameter slots included)
+        for p in params:
+            ddp.expect(True, p.grad)
+        for p in reversed(params):
+            p.grad.fill_(float(rank + 1))
+            ddp.done(p.grad)                                # buckets complete during "backward": host actions recorded in between
+        n_in_backward = sum(1 for k, _ in plan if k == "host")
+        assert n_in_backward >= 1, "bucket launches during backward must be recorded as host actions"
+        w.reduce_and_step(PlanOpt())
+        ddp.HOST_HOOK = None
+        kinds = [k for k, _ in plan]
+        ranges = [v for k, v in plan if k == "cmd" and v != "begin"]
+        assert len(ranges) == len(tr.buckets) and kinds.count("host") == 2 * len(tr.buckets) + 1, (len(ranges), kinds.count("host"))
+        assert torch.allclose(m.arena.grad, torch.full_like(m.arena.grad, 3.0)) and not w.launched and not w.ready
+        for i, (k, v) in enumerate(plan):                   # every range is preceded by a host action (the wait for ITS bucket)
+            if k == "cmd" and v != "begin":
+                assert plan[i - 1][0] == "host"
+        for rep in range(2):                                # replays: other gradients, no tracker calls, only the recorded sequence
+            gen = torch.Generator().manual_seed(50 + 10 * rep + rank)
+            mine = torch.randn(m.arena.n, generator=gen)
+            both = mine.clone()
+            dist.all_reduce(both)
+            m.arena.grad.copy_(mine)
+            stepped = torch.zeros(m.arena.n, dtype=torch.bool)
+            for k, v in plan:
+                if k == "host":
+                    v()
+                elif v != "begin":
+                    a, b = v
+                    assert torch.equal(m.arena.grad[a:b], both[a:b]), "a replayed range ran before its bucket's all-reduce"
+                    stepped[a:b] = True
+            assert stepped.all() and torch.equal(m.arena.grad, both)
+            assert not w.works and not w.launched and not w.ready and all(v == 0 for v in tr.pending.values())
         # expect() is ignored when the caller says no grad is needed (inference under no_grad)
         ddp.expect(False, params[0].grad)
         assert all(v == 0 for v in tr.pending.values())

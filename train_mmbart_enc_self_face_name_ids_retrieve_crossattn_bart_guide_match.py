@@ -76,7 +76,7 @@ parser.add_argument("--steps_per_epoch", type=int, default=20)
 parser.add_argument("--log_every", type=int, default=5)
 parser.add_argument("--val_steps", type=int, default=0, help="synthetic validation batches per epoch (eval_epoch, TRAIN:391-447); 0 = skip")
 parser.add_argument("--test_steps", type=int, default=0, help="synthetic test batches generated after training (TRAIN:480-530); 0 = skip")
-parser.add_argument("--launch_plan", default=True, type=_b, help="world 1: record the step's launch sequence once per batch shape and replay it from "
+parser.add_argument("--launch_plan", default=True, type=_b, help="record the step's launch sequence once per batch shape and replay it from "
                     "C++ (vacnic_amd.training.PlannedTrainStep: one C call per step instead of ~1400 Python round trips); False = eager")
 parser.add_argument("--resume", type=str, default="", help="checkpoint written by a previous run (<out_dir>/<experiment_name>last.pt): "
                     "weights, AdamW moments, LR-schedule position and dropout RNG are restored and the step count continues")
@@ -168,7 +168,7 @@ def run(args, batches=None):
             else:
                 batch = to_device(batch, "cuda")
             g_ = guide if not args.only_image else None
-            if world == 1 and getattr(args, "launch_plan", True):
+            if getattr(args, "launch_plan", True):
                 # one recorded plan per batch geometry (a collated shard batch is padded to its own maxima): the first batch of a
                 # geometry runs eagerly, the second is recorded while it runs, later ones are one replay each; at most 4 plans are kept
                 # (each owns a private allocator pool)

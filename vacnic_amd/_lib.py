@@ -177,6 +177,7 @@ _PLAIN_FNS = {
     "vacnic_beam_init": [C.POINTER(BeamState), i32, vp],
     "vacnic_wgrad_group": [C.POINTER(WgradJob), i64, vp],
     "vacnic_plan_end": [i64], "vacnic_plan_replay": [i64, i64, i64], "vacnic_plan_destroy": [i64], "vacnic_stream_fence": [vp, vp],
+    "vacnic_plan_pause": [i32],
     "vacnic_beam_step": [C.POINTER(BeamState), vp, vp, i32, i32, vp],
 }
 EXPORTED = sorted(list(_STRUCT_FNS) + list(_PLAIN_FNS) + ["vacnic_last_error_string", "vacnic_version", "vacnic_decoder_step_sync_bytes", "vacnic_decoder_step_slots_bytes",

@@ -41,10 +41,11 @@ static std::mutex g_mu;                          // plan table (begin / end / de
 static std::vector<Plan*> g_plans;
 static std::atomic<Plan*> g_rec{nullptr};
 static std::thread::id g_rec_tid;                // written before g_rec is published, read only when g_rec is non-null
+static int g_paused = 0;                         // vacnic_plan_pause: the recording thread's host-side actions launch without being recorded
 thread_local int depth = 0;
 // recording is bound to the thread that began it: a C-ABI call from any other thread (an autograd worker, a loader thread) while a
 // plan is open launches normally and is NOT frozen into the plan
-bool active() { return g_rec.load(std::memory_order_acquire) != nullptr && g_rec_tid == std::this_thread::get_id(); }
+bool active() { return g_rec.load(std::memory_order_acquire) != nullptr && g_rec_tid == std::this_thread::get_id() && g_paused == 0; }
 void push(std::function<int()> f) { g_rec.load(std::memory_order_relaxed)->cmds.push_back(std::move(f)); }
 size_t size() { return g_rec.load(std::memory_order_relaxed)->cmds.size(); }
 void truncate(size_t n) { auto& c = g_rec.load(std::memory_order_relaxed)->cmds; if (n < c.size()) c.resize(n); }
@@ -70,7 +71,17 @@ extern "C" int vacnic_plan_end(int64_t h) {
   VCHECK(p && p == vplan::g_rec.load() && vplan::g_rec_tid == std::this_thread::get_id(), VACNIC_BAD_SHAPE,
          "plan_end: plan %ld is not the one this thread is recording", (long)h);
   p->open = false;
+  vplan::g_paused = 0;
   vplan::g_rec.store(nullptr, std::memory_order_release);
+  return VACNIC_OK;
+}
+
+// While a plan is being recorded, work the HOST does at a mark (the DDP reducer's casts and collectives, anything the caller
+// repeats itself at every replay) must not be frozen into the plan: pause(1) ... pause(0) around it (nests).
+extern "C" int vacnic_plan_pause(int on) {
+  VCHECK(vplan::g_rec.load() != nullptr && vplan::g_rec_tid == std::this_thread::get_id(), VACNIC_BAD_SHAPE, "plan_pause: this thread is not recording a plan");
+  vplan::g_paused += on ? 1 : -1;
+  if (vplan::g_paused < 0) vplan::g_paused = 0;
   return VACNIC_OK;
 }
 
@@ -79,7 +90,9 @@ extern "C" int64_t vacnic_plan_size(int64_t h) {
   return p ? (int64_t)p->cmds.size() : -1;
 }
 
-extern "C" int64_t vacnic_plan_mark(void) { return vplan::active() ? (int64_t)vplan::size() : -1; }
+extern "C" int64_t vacnic_plan_mark(void) {
+  return (vplan::g_rec.load() != nullptr && vplan::g_rec_tid == std::this_thread::get_id()) ? (int64_t)vplan::size() : -1;
+}
 
 extern "C" int vacnic_plan_replay(int64_t h, int64_t first, int64_t last) {
   vplan::Plan* p = vplan::get(h);

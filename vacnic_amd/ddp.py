@@ -66,6 +66,16 @@ class GradTracker:
 
 
 TRACKER = None        # set by DistributedDataParallel when world_size > 1; ops.py consults it
+HOST_HOOK = None      # set by training.PlannedTrainStep while it records a launch plan: callable(fn) runs fn now AND at the same point
+                      # of every replay (the plan is split there).  The reducer's host-side work — waiting for the side streams,
+                      # launching a bucket's collective, making the compute stream wait for it — goes through _host().
+
+
+def _host(fn):
+    if HOST_HOOK is not None:
+        HOST_HOOK(fn)
+    else:
+        fn()
 
 
 def expect(need_grad, *tensors):
@@ -130,6 +140,10 @@ class DistributedDataParallel(torch.nn.Module):
             return
         self.launched.add(start)
         self.order.append(start)
+        _host(lambda: self._issue_bucket(start))
+
+    def _issue_bucket(self, start):
+        """host side of one bucket: the comm stream waits for the bucket's writers, then carries the (cast +) all-reduce."""
         end = self.bucket_end[start]
         g = self.arena.grad[start:end]
         s16 = self.stage16[start:end] if self.stage16 is not None else None
@@ -192,8 +206,8 @@ class DistributedDataParallel(torch.nn.Module):
         for start, _ in self.tracker.buckets:
             self._launch_bucket(start)
         for start in list(self.order):
-            self._wait_bucket(start)
-        self._finish()
+            _host(lambda s=start: self._wait_bucket(s))
+        _host(self._finish)
 
     def reduce_and_step(self, optimizer, clip_norm=None):
         """reduce_gradients() + optimizer.step(), pipelined: AdamW runs bucket by bucket in the order the all-reduces were
@@ -209,6 +223,6 @@ class DistributedDataParallel(torch.nn.Module):
             self._launch_bucket(start)
         optimizer.begin_step()
         for start in list(self.order):
-            self._wait_bucket(start)
+            _host(lambda s=start: self._wait_bucket(s))
             optimizer.step_range(start, self.bucket_end[start])
-        self._finish()
+        _host(self._finish)

@@ -735,6 +735,12 @@ def to_bf16(x):
 
 # ---------------------------------------------------------------------------------------------- losses
 LMHEAD_CHUNK = 16384        # vocabulary columns of dlogits alive at a time in the backward ([R, 16384] bf16 = 64 MiB at R = 2048)
+# dh += dlogits_c . E_c reduces over 16384 vocabulary columns into a [R, d] output: split-K.  Default: the K slices meet through the
+# GEMM's ordered fix-up (workspace + arrival tickets, include/vacnic_hip.h) — bitwise reproducible at the speed of the fp32
+# atomics it replaces (R = 2048: 89.7 vs 88.0 us per chunk, profiles/r4_gemm_fixup_vs_shipped.txt).  With atomics the summation
+# order varied whenever a second process shared the GPU, one bf16 element of dh rounded the other way about every second pass,
+# and backward amplified that to 1e-5 .. 2e-3 on every gradient (tools/grad_determinism.py).  VACNIC_LMHEAD_ATOMICS=1: round 3.
+LMHEAD_FIXUP = __import__("os").environ.get("VACNIC_LMHEAD_ATOMICS") != "1"
 
 
 class LmHeadCeFn(Function):
@@ -772,7 +778,10 @@ class LmHeadCeFn(Function):
             K.lmhead_ce_dlogits(h2, emb16_pad, tgt, V, rowp, dl, c0, n, ignore_index=ignore_index)
             ec = emb16_pad[c0:c0 + n8]
             # dh += dlogits_c . E_c: a reduction 8-16x longer than the output is wide -> split-K, fp32 accumulate
-            K.gemm(dl, ec, R, d, n8, out=dh32, ldx=CH, w_kstrided=True, out_mode=2, split_k=8)
+            if LMHEAD_FIXUP:
+                K.gemm(dl, ec, R, d, n8, out=dh32, ldx=CH, w_kstrided=True, out_mode=2, split_k=4, fixup=True, tile_hint=128)
+            else:
+                K.gemm(dl, ec, R, d, n8, out=dh32, ldx=CH, w_kstrided=True, out_mode=2, split_k=8)
             if egrad is not None:                                  # dE[c0:c0+n] += dlogits_c^T h
                 tiles = ((n + 127) // 128) * ((d + 127) // 128)
                 K.gemm(dl, h2, n, d, R, out=egrad[c0:c0 + n], ldx=CH, ldw=d, ldo=d, x_kstrided=True, w_kstrided=True, out_mode=2,

@@ -395,8 +395,9 @@ class PlannedTrainStep:
     What makes a step replayable: explicit scheduling (streams.explicit(): no stream synchronisation hidden inside torch), no
     host<->device sync and no ATen kernel inside the step, per-step scalars in device memory (LR, step and dropout counters:
     vacnic_lr_step), and every buffer at its recorded address — the recording runs inside a private allocator pool that is
-    kept, inputs are copied into static tensors before each replay.  world_size 1 (the DDP reducer launches its collectives
-    from Python between backward nodes; it keeps the eager path)."""
+    kept, inputs are copied into static tensors before each replay.  world_size > 1: the DDP reducer's host-side work (bucket
+    all-reduces launched on the comm stream as backward completes them, the waits before each bucket's AdamW range) is registered
+    as host actions at marks of the plan (ddp.HOST_HOOK -> self.host) and repeated by the host at the same points of every replay."""
 
     def __init__(self, model, guide, optimizer, args: TrainArgs, example_batch, warmup=2, towers=None):
         """towers: a FrozenTowerGraphs — the two frozen networks then stay hipGraph replays on their own streams, launched by the
@@ -404,8 +405,7 @@ class PlannedTrainStep:
         host joins them (before the CoLaM loss) and releases their static outputs (after it)."""
         global _PLAN
         from . import _lib
-        if isinstance(model, DistributedDataParallel) and model.world > 1:
-            raise RuntimeError("PlannedTrainStep: world_size 1 only (the reducer's bucket launches are host-side)")
+        from . import ddp as _ddp
         if streams.enabled() and not streams.explicit():
             raise RuntimeError("PlannedTrainStep needs explicit scheduling (VACNIC_EXPLICIT_STREAMS=0 is set)")
         self.towers = towers
@@ -422,18 +422,23 @@ class PlannedTrainStep:
         if self.handle < 0:
             _lib.check(1)
         _PLAN = self
+        # world > 1: the reducer's host-side work (bucket launches on the comm stream as backward completes them, the waits before
+        # each bucket's AdamW range) becomes host actions at marks of the plan — N ranks then run the SAME launch path as one
+        _ddp.HOST_HOOK = self.host
         try:
             with torch.cuda.use_mem_pool(self.pool):
                 self.out4 = train_step(model, guide, optimizer, self.static, args, None, towers)
         except BaseException:
             # a recording that raised leaves neither a half-recorded plan nor its private pool behind
             _PLAN = None
+            _ddp.HOST_HOOK = None
             _lib.lib.vacnic_plan_end(self.handle)
             _lib.lib.vacnic_plan_destroy(self.handle)
             self.handle = None
             self.pool = None
             raise
         _PLAN = None
+        _ddp.HOST_HOOK = None
         _lib.check(_lib.lib.vacnic_plan_end(self.handle))
         torch.cuda.synchronize()
         self.commands = int(_lib.lib.vacnic_plan_size(self.handle))
@@ -444,6 +449,17 @@ class PlannedTrainStep:
         self.marks.append((int(_lib.lib.vacnic_plan_mark()), what))
         self._at(what)
 
+    def host(self, fn):
+        """recording: register `fn` as a host action at this point of the plan and run it now, unrecorded (whatever it launches
+        through the C-ABI is the host's to repeat at every replay, not the plan's)."""
+        from . import _lib
+        self.marks.append((int(_lib.lib.vacnic_plan_mark()), fn))
+        _lib.check(_lib.lib.vacnic_plan_pause(1))
+        try:
+            fn()
+        finally:
+            _lib.check(_lib.lib.vacnic_plan_pause(0))
+
     def _before(self, batch=None, ready=None):
         if self.towers is not None:
             late = self.ev_bwd if __import__("os").environ.get("VACNIC_GUIDE_LATE", "0") == "1" else None
@@ -451,7 +467,9 @@ class PlannedTrainStep:
             torch.cuda.current_stream().wait_event(self.towers.ev_vit)         # the student's encoder needs the image feature
 
     def _at(self, what):
-        if what == "join_guide":
+        if callable(what):
+            what()
+        elif what == "join_guide":
             torch.cuda.current_stream().wait_stream(streams.aux_stream())
         elif what == "towers_consumed":
             self.towers.mark_consumed()
