@@ -23,6 +23,15 @@ Planted structure (one source, two decoding paths because `forced_bos_token_id=0
 The EOS row is also the decoder start token's input embedding, so the construction is iterated to a fixed point.
 
     python oracle/cfg5_fixture.py        # writes tests/golden/cfg5_planted.npz (ids + rows: INPUT data of the fixture)
+    python oracle/cfg5_fixture.py m4     # writes tests/golden/cfg5_planted_m4.npz: the SENSITIVE variant (below)
+
+Variant "m4" (round 4: is the fixture able to catch a fault?).  The 40-unit margin above forgives any fault that moves a logit by
+less than ~40 units.  In m4 every planted token wins by only 4 .. 7 logit units (bf16 noise of the decoder stack: < 0.5, still 8x
+smaller; the margin varies with the position so that the runner-up beams of neighbouring positions are not tied), EOS beats the
+chain token at T_EOS by 1.5, and the hub-defaults path carries an N-GRAM TRAP: the bigram (a, b) of positions 10-11 returns at
+positions 30-31, and at position 32 the token c that followed it the first time is planted as the BEST candidate, 2 units above
+the chain's real next token — only the no-repeat-3-gram ban keeps the caption on the chain.  tests/test_model_gpu.py mutates the
+decoder (a corrupted KV-cache row, a skipped beam reorder, a dropped ban) and asserts that the ids / n-best lists CHANGE.
 
 oracle/make_golden.py::run_generate_cfg5_case then runs transformers' beam search over the REAL reference model with these
 weights and stores the sequences (tests/golden/generate_cfg5.npz).
@@ -41,6 +50,16 @@ from vacnic_amd import synthetic
 from vacnic_amd.config import VacnicConfig
 
 PLANTED = os.path.join(ROOT, "tests", "golden", "cfg5_planted.npz")
+PLANTED_M4 = os.path.join(ROOT, "tests", "golden", "cfg5_planted_m4.npz")
+# the sensitive variant: margins, the n-gram trap of path H (positions of the first / second occurrence of the bigram)
+M4_MARGIN, M4_EOS_OVER, M4_TRAP_OVER = 4.0, 1.5, 2.0
+TRAP_I, TRAP_J = 10, 30
+
+
+def m4_margin(t):
+    """per-position margin of variant m4: 4 .. 7 logit units, never equal at neighbouring positions."""
+    return M4_MARGIN + 0.75 * ((7 * t) % 5)
+
 MAX_LENGTH, NUM_BEAMS, LENGTH_PENALTY = 50, 5, 2.0
 T_EOS = 24                             # cur_len at which the planted EOS wins on path P
 MARGIN = 40.0                          # logit units by which a planted token beats the best other token (bf16 noise here: < 0.5)
@@ -109,8 +128,107 @@ def expected(planted=None):
     if planted is None:
         planted = np.load(PLANTED)
     P, Hh = planted["path_P"].tolist(), planted["path_H"].tolist()
+    if "plain_ends_early" in planted and not bool(planted["plain_ends_early"]):
+        # variant m4: with 4-unit margins a position's log-probability is not ~0 (thousands of noise tokens share the softmax), so
+        # under length_penalty 2.0 the full-length chain out-scores the hypothesis that ended at T_EOS: the plain case runs on
+        return {"plain": P[:MAX_LENGTH - 1] + [2], "full50": P[:MAX_LENGTH - 1] + [2],
+                "hub": Hh[:MAX_LENGTH - 1] + [2], "hub_full50": Hh[:MAX_LENGTH - 1] + [2]}
     return {"plain": P[:T_EOS] + [2], "full50": P[:MAX_LENGTH - 1] + [2],
             "hub": Hh[:MAX_LENGTH - 1] + [2], "hub_full50": Hh[:MAX_LENGTH - 1] + [2]}
+
+
+def plant_m4():
+    """variant m4 (see the module docstring): small per-position margins, EOS over the chain by 1.5, n-gram trap on path H.
+    Rows are built INCREMENTALLY (a token that occurs at several positions — the trap's bigram, the trap token — gets one component
+    per position; the position states are nearly orthogonal) and iterated to a fixed point."""
+    from oracle import vacnic_oracle as O
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    cfg = cfg5_cfg()
+    sd = base_state_dict(cfg)
+    E0 = sd["model.shared.weight"]
+    E = E0.clone()
+    batch, img = inputs(cfg)
+    src = batch["article_ids"]
+    mask = O.create_src_mask_bart(src)
+    kw = dict(name_ids=batch["names_art_ids"], name_mask=O.create_src_mask_bart(batch["names_art_ids"]),
+              face_features=batch["face_emb"], face_mask=O.create_src_mask_bart(batch["face_emb"][:, :, -1]))
+    g = np.random.default_rng(2024)
+    pool = [int(t) for t in g.permutation(np.arange(1000, 50000))[:256]]
+    chains = {"P": [2] + pool[:MAX_LENGTH - 2], "H": [2, 0] + pool[64:64 + MAX_LENGTH - 3]}
+    Hc = chains["H"]
+    Hc[TRAP_J], Hc[TRAP_J + 1] = Hc[TRAP_I], Hc[TRAP_I + 1]                       # the bigram (a, b) returns
+    trap_tok, trap_t = Hc[TRAP_I + 2], TRAP_J + 2                                   # c: banned at position TRAP_J + 2 by no_repeat_ngram_size 3
+    assert len(set(Hc[2:])) == len(Hc[2:]) - 2 and Hc[trap_t] != trap_tok
+    ids = sorted(set(chains["P"][1:] + Hc[2:]) | {2})
+    NEG = -1e30
+
+    def sweep(write):
+        sd["model.shared.weight"] = E
+        enc_h = O.encoder(sd, cfg, src, mask, img, kw["name_ids"], kw["name_mask"], kw["face_features"], kw["face_mask"])[0]
+        worst, eos_over, trap_over, eos_row = 1e9, None, None, None
+        for name, seq in chains.items():
+            for t in range(2 if name == "H" else 1, MAX_LENGTH - 1):
+                h = O.decoder(sd, cfg, torch.tensor([seq[:t]]), enc_h, mask)[-1][0, -1]
+                logits = E @ h
+                d = h / h.norm() - mu
+                d = d / d.norm()
+                c = float(d @ h)
+                want = seq[t]
+                eos_step = name == "P" and t == T_EOS
+                trap_step = name == "H" and t == trap_t
+                others = logits.clone()
+                others[want] = NEG
+                if eos_step:
+                    others[2] = NEG
+                    eos_over = float(logits[2] - logits[want])
+                if trap_step:
+                    others[trap_tok] = NEG
+                    trap_over = float(logits[trap_tok] - logits[want])
+                worst = min(worst, float(logits[want] - others.max()) - (m4_margin(t) - M4_MARGIN))
+                if write:
+                    target = float(others.max()) + m4_margin(t)
+                    E[want] = E[want] + d * ((target - float(logits[want])) / c)
+                    if eos_step:
+                        eos_row = E[2] + d * ((target + M4_EOS_OVER - float(logits[2])) / c)
+                    if trap_step:
+                        E[trap_tok] = E[trap_tok] + d * ((target + M4_TRAP_OVER - float(logits[trap_tok])) / c)
+        return worst, eos_over, trap_over, eos_row
+
+    with torch.no_grad():
+        sd["model.shared.weight"] = E
+        enc_h = O.encoder(sd, cfg, src, mask, img, kw["name_ids"], kw["name_mask"], kw["face_features"], kw["face_mask"])[0]
+        st0 = O.decoder(sd, cfg, torch.tensor([chains["P"]]), enc_h, mask)[-1][0]
+        mu = (st0 / st0.norm(dim=1, keepdim=True)).mean(0)
+        for rnd in range(40):
+            _, _, _, eos_row = sweep(True)
+            E[2] = eos_row
+            worst, eos_over, trap_over, _ = sweep(False)
+            print(f"round {rnd}: smallest chain margin (minus its position's spread) {worst:.3f}, EOS over the chain token {eos_over:.3f}, "
+                  f"trap token over the chain token {trap_over:.3f}", flush=True)
+            if worst >= M4_MARGIN - 0.1 and abs(eos_over - M4_EOS_OVER) <= 0.1 and abs(trap_over - M4_TRAP_OVER) <= 0.1:
+                break
+        assert worst >= M4_MARGIN - 0.25 and abs(eos_over - M4_EOS_OVER) <= 0.25 and abs(trap_over - M4_TRAP_OVER) <= 0.25, (worst, eos_over, trap_over)
+    planted = {"ids": np.array(ids, dtype=np.int64), "rows": E[torch.tensor(ids)].numpy().astype(np.float32),
+               "path_P": np.array(chains["P"], dtype=np.int64), "path_H": np.array(chains["H"], dtype=np.int64),
+               "trap": np.array([TRAP_I, TRAP_J, trap_t, trap_tok], dtype=np.int64)}
+    sdf = state_dict(cfg, planted)
+    out = O.beam_search_decode(sdf, cfg, src, mask, img, NUM_BEAMS, MAX_LENGTH, LENGTH_PENALTY, forced_eos_token_id=2, **kw)
+    planted["plain_ends_early"] = np.array(out.shape[1] == T_EOS + 1)
+    exp = expected(planted)
+    for name, extra in CASES:
+        out, nbest = O.beam_search_decode(sdf, cfg, src, mask, img, NUM_BEAMS, MAX_LENGTH, LENGTH_PENALTY, forced_eos_token_id=2,
+                                          return_nbest=True, **extra, **kw)
+        assert out[0].tolist() == exp[name], (name, out[0].tolist(), exp[name])
+        if name == "plain":                                  # the hypothesis that ended at T_EOS is in the n-best list either way
+            assert any(sq == chains["P"][:T_EOS] for _, sq in nbest[0]), [len(sq) for _, sq in nbest[0]]
+        print(f"oracle beam search, case {name}: {out.shape[1]} tokens ok; n-best scores {[round(s, 4) for s, _ in nbest[0]]}", flush=True)
+    # the trap works: without the ban the hub path leaves the chain at the trap position
+    out = O.beam_search_decode(sdf, cfg, src, mask, img, NUM_BEAMS, MAX_LENGTH, LENGTH_PENALTY, forced_eos_token_id=2,
+                               early_stopping=True, forced_bos_token_id=0, **kw)
+    assert out[0].tolist() != exp["hub"] and int(out[0, trap_t]) == trap_tok, ("the trap must spring without the ban", out[0].tolist())
+    print("without no_repeat_ngram_size the caption takes the trap token at position", trap_t, flush=True)
+    np.savez_compressed(PLANTED_M4, **planted)
+    print("wrote", PLANTED_M4, os.path.getsize(PLANTED_M4), "bytes")
 
 
 def _plant():
@@ -193,4 +311,7 @@ def _plant():
 
 
 if __name__ == "__main__":
-    _plant()
+    if len(sys.argv) > 1 and sys.argv[1] == "m4":
+        plant_m4()
+    else:
+        _plant()

@@ -255,6 +255,7 @@ def run_generate_cfg5_case(mfull, train):
     from oracle import cfg5_fixture as F5
     cfg = F5.cfg5_cfg()
     sd = F5.state_dict(cfg)
+    sd_m4 = F5.state_dict(cfg, np.load(F5.PLANTED_M4))
 
     class Oracle(mfull.BartForMultiModalGeneration, GenerationMixin):
         pass
@@ -273,6 +274,26 @@ def run_generate_cfg5_case(mfull, train):
         rec[name] = out.numpy()
         print("generate cfg5", name, tuple(out.shape), out[0, :8].tolist(), "...", out[0, -3:].tolist())
     np.savez_compressed(os.path.join(OUT, "generate_cfg5.npz"), **rec)
+    # ---- the sensitive variant (cfg5_fixture "m4": 4 .. 7-unit margins, n-gram trap): best sequence AND the whole n-best list
+    # (num_return_sequences = num_beams: sequences + sequences_scores of BeamSearchScorer.finalize) of the reference
+    mfull.BartForMultiModalGeneration = Oracle
+    m4 = build_ref_model(mfull, cfg, sd_m4)
+    mfull.BartForMultiModalGeneration = orig
+    rec = {}
+    for name, extra in F5.CASES:
+        o = m4.generate(input_ids=src, attention_mask=mask, num_beams=F5.NUM_BEAMS, max_length=F5.MAX_LENGTH,
+                        length_penalty=F5.LENGTH_PENALTY, use_cache=False, do_sample=False, num_return_sequences=F5.NUM_BEAMS,
+                        output_scores=True, return_dict_in_generate=True, **extra, **kw)
+        seqs = o.sequences.numpy()
+        rec[name] = seqs[:1, :int((seqs[0] != 1).sum())]                  # best hypothesis without its padding
+        rec[name + "_nbest"] = seqs
+        rec[name + "_nbest_scores"] = o.sequences_scores.numpy().astype(np.float64)
+        print("generate cfg5 m4", name, tuple(seqs.shape), "scores", [round(float(v), 5) for v in o.sequences_scores], "lens", (seqs != 1).sum(1).tolist())
+    # without the ban the reference walks into the n-gram trap (the fixture's sensitivity claim, pinned by the reference itself)
+    o = m4.generate(input_ids=src, attention_mask=mask, num_beams=F5.NUM_BEAMS, max_length=F5.MAX_LENGTH, length_penalty=F5.LENGTH_PENALTY,
+                    use_cache=False, do_sample=False, early_stopping=True, forced_bos_token_id=0, **kw).sequences
+    rec["hub_without_ngram_ban"] = o.numpy()
+    np.savez_compressed(os.path.join(OUT, "generate_cfg5_m4.npz"), **rec)
 
 
 def run_helpers(train, BatchSoftmax):

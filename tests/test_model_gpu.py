@@ -490,6 +490,133 @@ def test_config5_batch1_beam5_maxlen50_matches_reference_golden(variant, monkeyp
         s_.dec.check_step_kernel()
 
 
+def _ref_nbest(g, name, lp):
+    """[(sum of log-probabilities, ids)] of the reference's n-best golden (sequences padded with 1, scores length-normalised)."""
+    out = []
+    for sq, sc in zip(g[name + "_nbest"], g[name + "_nbest_scores"]):
+        ids = [int(t) for t in sq if int(t) != 1]
+        out.append((float(sc) * (len(ids) - 1) ** lp, ids))
+    return out
+
+
+def _nbest_mismatch(got, want, lp, max_length, tol=0.5):
+    """None when the n-best list `got` [(normalised score, ids without the closing EOS)] agrees with the reference's `want`
+    [(sum, ids)], else a description.  bf16 moves a 49-position sum of log-probabilities by a few tenths, so: the sorted sums agree
+    within `tol`; a hypothesis whose reference sum is separated from every other by more than 2 tol must sit at the same rank with
+    the same ids; the others (near ties: their order is noise) must match some reference hypothesis within tol of their sum."""
+    if len(got) != len(want):
+        return f"{len(got)} hypotheses, reference {len(want)}"
+    gs = []
+    for sc, ids in got:
+        full = ids + [2] if (len(ids) < max_length and ids[-1] != 2) else ids
+        gs.append((sc * len(ids) ** lp, full))
+    for k, ((a, _), (b, _)) in enumerate(zip(gs, want)):
+        if abs(a - b) > tol:
+            return f"rank {k}: sum of log-probabilities {a:.3f}, reference {b:.3f}"
+    for k, (b, wids) in enumerate(want):
+        if all(abs(b - o) > 2 * tol for j, (o, _) in enumerate(want) if j != k):
+            if gs[k][1] != wids:
+                return f"rank {k} (clearly separated): ids differ"
+    for k, (a, ids) in enumerate(gs):
+        if not any(ids == wids and abs(a - b) <= tol for b, wids in want):
+            return f"rank {k}: no reference hypothesis with these ids near its score"
+    return None
+
+
+def test_config5_sensitive_fixture_all_beams_and_mutations(monkeypatch):
+    """Is the configs[4] fixture able to catch a fault?  Variant m4 of oracle/cfg5_fixture.py plants every token with a margin of
+    only 4 .. 7 logit units (bf16 noise < 0.5), EOS 1.5 over the chain, and an n-gram trap that only the no-repeat-3-gram ban
+    keeps the caption out of; the golden holds the reference's best sequence AND its five final beams with their scores.
+      1. the healthy decoder (persistent step kernel, device beams; host scorer; hipGraph replay) reproduces the best ids of all
+         four cases exactly and the whole n-best list (ids + scores of all five beams);
+      2. MUTATIONS must be caught: (a) one corrupted KV-cache position, (b) beam reorders skipped (caches no longer follow their
+         beams), (c) the n-gram bans dropped — each changes the generated ids or the n-best list, (c) into exactly the sequence the
+         REFERENCE generates without the ban."""
+    from oracle import cfg5_fixture as F5
+    from vacnic_amd import generate as Gn, kernels as K, synthetic
+    from vacnic_amd.config import ClipVisionConfig
+    from vacnic_amd.training import build_models
+    gold = np.load(os.path.join(G, "generate_cfg5_m4.npz"))
+    planted = np.load(F5.PLANTED_M4)
+    trap_t, trap_tok = int(planted["trap"][2]), int(planted["trap"][3])
+    cfg = F5.cfg5_cfg()
+    vcfg = ClipVisionConfig(width=128, layers=1, patch_size=16, image_size=32, output_dim=64)
+    sd = F5.state_dict(cfg, planted)
+    model, _, _ = build_models(cfg, vcfg, init="synthetic",
+                               state_dicts=(sd, synthetic.make_state_dict(synthetic.guide_bart_param_shapes(cfg), seed=2),
+                                            synthetic.make_state_dict(synthetic.clip_visual_param_shapes(vcfg), seed=4, std=0.05)))
+    model.eval()
+    batch, img = F5.inputs(cfg)
+    dev = {k: v.cuda() for k, v in batch.items()}
+    mask, _ = K.prep_ids(dev["article_ids"], 1)
+    nmask, _ = K.prep_ids(dev["names_art_ids"], 1)
+    monkeypatch.setenv("VACNIC_DECODE_BARRIER", "0"); monkeypatch.setenv("VACNIC_DECODE_PER_OP", "0")
+    LP, ML = F5.LENGTH_PENALTY, F5.MAX_LENGTH
+
+    def run(extra, **kw):
+        return model.generate(input_ids=dev["article_ids"], attention_mask=mask, num_beams=F5.NUM_BEAMS, max_length=ML, length_penalty=LP,
+                              image_features=img.cuda(), face_features=dev["face_emb"], face_mask=K.face_mask(dev["face_emb"]),
+                              name_ids=dev["names_art_ids"], name_mask=nmask, add_ner_ffn=True, return_nbest=True, **extra, **kw)
+    cases = dict(F5.CASES)
+    # ---- 1. healthy: every case, all five beams; eager, graph capture + replay, host-side scorer
+    for name, extra in F5.CASES:
+        want, want_nb = torch.from_numpy(gold[name]), _ref_nbest(gold, name, LP)
+        for leg in ("eager", "capture", "replay", "host"):
+            got, nbest = run(extra, device_beams=False) if leg == "host" else run(extra)
+            assert torch.equal(got.cpu(), want), (name, leg, got.tolist(), want.tolist())
+            bad = _nbest_mismatch(nbest[0], want_nb, LP, ML)
+            assert bad is None, (name, leg, bad, [(round(s * len(i) ** LP, 3), len(i)) for s, i in nbest[0]], [(round(s, 3), len(i)) for s, i in want_nb])
+    assert any(s_.graphs for s_ in model._decode_sessions.values()), "graph replay path was not exercised"
+    name = "hub_full50"
+    want, want_nb = torch.from_numpy(gold[name]), _ref_nbest(gold, name, LP)
+
+    def mutated(**kw):
+        model.__dict__.pop("_decode_sessions", None)               # fresh sessions: eager positions, so the patched methods run
+        got, nbest = run(cases[name], use_graphs=False, **kw)
+        return got.cpu(), nbest[0]
+
+    # ---- 2a. one KV-cache position corrupted (keys and values of position 5, every layer, negated from position 20 on)
+    orig_step = Gn.CachedDecoder.step
+
+    def step_corrupt(self, ids_t, t):
+        if t == 20:
+            self.cache_at(t)[:, :, 5, :].neg_()
+        return orig_step(self, ids_t, t)
+    for kw in ({}, {"device_beams": False}):
+        monkeypatch.setattr(Gn.CachedDecoder, "step", step_corrupt)
+        got, nb = mutated(**kw)
+        monkeypatch.setattr(Gn.CachedDecoder, "step", orig_step)
+        assert not torch.equal(got, want) or _nbest_mismatch(nb, want_nb, LP, ML) is not None, ("a corrupted KV-cache position went unnoticed", kw)
+    # ---- 2b. the caches stop following their beams (identity permutation instead of the beam indices)
+    orig_reorder = Gn.CachedDecoder.reorder
+
+    def reorder_skip(self, beam_idx, t):
+        return orig_reorder(self, torch.arange(beam_idx.numel(), device=beam_idx.device, dtype=beam_idx.dtype), t)
+    monkeypatch.setattr(Gn.CachedDecoder, "reorder", reorder_skip)
+    got, nb = mutated()
+    monkeypatch.setattr(Gn.CachedDecoder, "reorder", orig_reorder)
+    bad = _nbest_mismatch(nb, want_nb, LP, ML)
+    assert not torch.equal(got, want) or bad is not None, "skipped beam reorders went unnoticed (best beam AND n-best list unchanged)"
+    # ---- 2c. the n-gram bans dropped: the caption walks into the trap, exactly as the reference does without the ban
+    orig_body = Gn.DecodeSession.body
+
+    def body_no_bans(self, t):
+        if self.bans_s is not None:
+            self.bans_s.fill_(-1)
+        return orig_body(self, t)
+    monkeypatch.setattr(Gn.DecodeSession, "body", body_no_bans)
+    got, _ = mutated()
+    monkeypatch.setattr(Gn.DecodeSession, "body", orig_body)
+    assert not torch.equal(got, want) and int(got[0, trap_t]) == trap_tok, ("dropped n-gram bans went unnoticed", got.tolist())
+    no_ban = torch.from_numpy(gold["hub_without_ngram_ban"])
+    got_nb, _ = run(dict(early_stopping=True, forced_bos_token_id=0, min_length=49), use_graphs=False)   # the un-mutated decoder without the processor
+    assert int(no_ban[0, trap_t]) == trap_tok and int(got_nb[0, trap_t]) == trap_tok
+    model.__dict__.pop("_decode_sessions", None)
+    # ---- and the healthy decoder is still healthy after the patches are gone
+    got, nbest = run(cases[name], use_graphs=False)
+    assert torch.equal(got.cpu(), want) and _nbest_mismatch(nbest[0], want_nb, LP, ML) is None
+
+
 def test_beam_topk_kernel_matches_torch():
     from vacnic_amd import kernels as K
     V, ld, R, Kc = 50267, 50272, 6, 10

@@ -232,3 +232,42 @@ def test_oracle_config5_beam_search_matches_reference_golden():
                                        **extra, **kw)
             assert np.array_equal(out.numpy(), g[name]), (name, out.tolist(), g[name].tolist())
     assert g["plain"].shape[1] == F5.T_EOS + 1 and g["full50"].shape[1] == 50 and g["hub_full50"].shape[1] == 50
+
+
+def _nbest_sums(seqs, scores, lp):
+    """(sum of log-probabilities, ids without padding) per returned hypothesis of a reference n-best golden."""
+    out = []
+    for sq, sc in zip(seqs, scores):
+        ids = [int(t) for t in sq if int(t) != 1]
+        out.append((float(sc) * (len(ids) - 1) ** lp, ids))
+    return out
+
+
+def test_oracle_config5_sensitive_fixture_nbest_matches_reference_golden():
+    """the SENSITIVE configs[4] fixture (oracle/cfg5_fixture.py variant m4: 4 .. 7-unit margins, EOS 1.5 over the chain, n-gram
+    trap): the oracle's beam search must reproduce the reference's best sequence AND its whole n-best list (ids and scores of all
+    five final beams, tests/golden/generate_cfg5_m4.npz), and the reference itself walks into the trap without the ban."""
+    from oracle import cfg5_fixture as F5
+    g = np.load(os.path.join(G, "generate_cfg5_m4.npz"))
+    planted = np.load(F5.PLANTED_M4)
+    exp = F5.expected(planted)
+    trap_t, trap_tok = int(planted["trap"][2]), int(planted["trap"][3])
+    assert g["hub_without_ngram_ban"][0].tolist() != exp["hub"] and int(g["hub_without_ngram_ban"][0, trap_t]) == trap_tok
+    cfg = F5.cfg5_cfg()
+    sd = F5.state_dict(cfg, planted)
+    batch, img = F5.inputs(cfg)
+    src = batch["article_ids"]; mask = O.create_src_mask_bart(src)
+    kw = dict(face_features=batch["face_emb"], face_mask=O.create_src_mask_bart(batch["face_emb"][:, :, -1]),
+              name_ids=batch["names_art_ids"], name_mask=O.create_src_mask_bart(batch["names_art_ids"]))
+    for name, extra in F5.CASES:
+        assert g[name][0].tolist() == exp[name], name
+        if name in ("plain", "hub_full50"):
+            out, nbest = O.beam_search_decode(sd, cfg, src, mask, img, F5.NUM_BEAMS, F5.MAX_LENGTH, F5.LENGTH_PENALTY, forced_eos_token_id=2,
+                                              return_nbest=True, **extra, **kw)
+            assert out[0].tolist() == g[name][0].tolist(), name
+            want = _nbest_sums(g[name + "_nbest"], g[name + "_nbest_scores"], F5.LENGTH_PENALTY)
+            assert len(nbest[0]) == len(want) == F5.NUM_BEAMS
+            for (sc, ids), (wsum, wids) in zip(nbest[0], want):          # fp32 against fp32: same order, same ids, same scores
+                got_ids = ids + [2] if len(ids) < F5.MAX_LENGTH and wids[-1] == 2 and ids[-1] != 2 else ids
+                assert got_ids == wids, (name, got_ids, wids)
+                assert abs(sc * len(ids) ** F5.LENGTH_PENALTY - wsum) <= 2e-3 * max(1.0, abs(wsum)), (name, sc * len(ids) ** 2, wsum)

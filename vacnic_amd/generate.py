@@ -447,12 +447,14 @@ class DecodeSession:
 def generate(model, input_ids=None, attention_mask=None, num_beams=1, max_length=20, length_penalty=1.0, early_stopping=False,
              no_repeat_ngram_size=0, min_length=0, forced_eos_token_id="config", forced_bos_token_id=None, image_features=None,
              face_features=None, face_mask=None, name_ids=None, name_mask=None, add_ner_ffn=True, use_graphs=True, device_beams=True,
-             **unused):
+             return_nbest=False, **unused):
     """GenerationMixin.generate(do_sample=False) semantics of transformers 4.18 for this model (greedy = 1 beam).
     Returns int64 [B, L] starting with decoder_start_token_id, padded with pad_token_id.
     Keyword defaults are the LIBRARY defaults; the defaults a hub checkpoint's config.json adds on top (what the reference's
     `model.generate(num_beams, max_length)` inherits after from_pretrained, TRAIN:513-520) are config.HUB_GENERATION_DEFAULTS and
-    are passed explicitly by the trainer-level callers (training.gen_caption_from_loader_bart, utils/test_mmbart_clip_ddp.py)."""
+    are passed explicitly by the trainer-level callers (training.gen_caption_from_loader_bart, utils/test_mmbart_clip_ddp.py).
+    return_nbest: also return, per batch item, the finalized n-best list [(length-normalised score, ids)], best first — what
+    `num_return_sequences=num_beams, output_scores=True` exposes as sequences / sequences_scores (the bookkeeping of ALL beams)."""
     cfg = model.config
     if model.arena is None:
         raise RuntimeError("call model.finalize(device) first")
@@ -498,7 +500,7 @@ def generate(model, input_ids=None, attention_mask=None, num_beams=1, max_length
                 model.train()
             raise
         ses.captions += 1
-        out = []
+        out, nbest = [], []
         for b in range(B):
             hy = _BeamHyps(nb, length_penalty, early_stopping)
             for i in range(int(hcnt[b])):
@@ -508,7 +510,9 @@ def generate(model, input_ids=None, attention_mask=None, num_beams=1, max_length
             if not bool(done_t[b]):
                 for j in range(nb):                       # BeamSearchScorer.finalize: open beams join the n-best list
                     hy.add(seqs_t[b * nb + j, :cur_len].tolist(), float(scores_t[b * nb + j]))
-            out.append(sorted(hy.beams, key=lambda x: x[0])[-1][1])
+            ranked = sorted(hy.beams, key=lambda x: x[0])
+            out.append(ranked[-1][1])
+            nbest.append([(float(sc), list(sq)) for sc, sq in reversed(ranked)])
         L = min(max(len(o) for o in out) + 1, max_length)
         res = torch.full((B, L), pad, dtype=torch.long)
         for b, o in enumerate(out):
@@ -517,7 +521,7 @@ def generate(model, input_ids=None, attention_mask=None, num_beams=1, max_length
                 res[b, len(o)] = eos
         if was_training:
             model.train()
-        return res.to(enc_h.device)
+        return (res.to(enc_h.device), nbest) if return_nbest else res.to(enc_h.device)
 
     seqs = [[start] for _ in range(R)]
     beam_scores = [0.0 if (r % nb) == 0 else -1e9 for r in range(R)]
@@ -574,12 +578,14 @@ def generate(model, input_ids=None, attention_mask=None, num_beams=1, max_length
         if all(done) or cur_len >= max_length:
             break
     ses.captions += 1
-    out = []
+    out, nbest = [], []
     for b in range(B):
         if not done[b]:
             for j in range(nb):
                 hyps[b].add(seqs[b * nb + j], float(beam_scores[b * nb + j]))
-        out.append(sorted(hyps[b].beams, key=lambda x: x[0])[-1][1])
+        ranked = sorted(hyps[b].beams, key=lambda x: x[0])
+        out.append(ranked[-1][1])
+        nbest.append([(float(sc), list(sq)) for sc, sq in reversed(ranked)])
     L = min(max(len(o) for o in out) + 1, max_length)
     res = torch.full((B, L), pad, dtype=torch.long)
     for b, o in enumerate(out):
@@ -588,4 +594,4 @@ def generate(model, input_ids=None, attention_mask=None, num_beams=1, max_length
             res[b, len(o)] = eos
     if was_training:
         model.train()
-    return res.to(dev)
+    return (res.to(dev), nbest) if return_nbest else res.to(dev)

@@ -110,24 +110,31 @@ def _load_tuned():
 _load_tuned()
 
 
+_TUNED_FIXUP = __import__("os").environ.get("VACNIC_GEMM_FIXUP_TUNED", "1") != "0"      # A/B: 0 = ignore the fix-up entries of gemm_tuned.json
 _FIX = {}                 # launch stream -> [workspace (uint8), counters (int32, all zero between launches)]
+_FIX_CAPTURE = {}         # the same for launches recorded by a hipGraph capture on that stream (buffers from the graph's private pool)
 _FIX_OLD = []             # outgrown workspaces: kernels already enqueued may still use them
 
 
 def _fix_buffers(stream, M, N, split_k):
     """split-K fix-up buffers of the launch stream: launches on ONE stream run in order, so they share a workspace that only
-    grows (persistent: the same addresses at every replay of a launch plan or a hipGraph), and the arrival counters, which every
-    launch leaves zeroed.  Kept out of torch's per-step allocations on purpose."""
+    grows (persistent: the same addresses at every replay of a launch plan), and the arrival counters, which every launch leaves
+    zeroed.  Kept out of torch's per-step allocations on purpose.  The counters of a new buffer are cleared by a memset node ON THE
+    LAUNCH STREAM (ordered before the GEMM whatever stream torch considers current; legal inside a stream capture).  Launches
+    recorded by a hipGraph capture get buffers of their own (allocated from the graph's pool): a captured launch and an eager
+    one must never share counters, and graphs captured on one stream replay in order."""
     need = int(_lib.lib.vacnic_gemm_workspace_bytes(M, N, split_k))
     ncnt = int(_lib.lib.vacnic_gemm_counters(M, N))
-    ent = _FIX.get(stream)
+    table = _FIX_CAPTURE if torch.cuda.is_current_stream_capturing() else _FIX
+    ent = table.get(stream)
     if ent is None or ent[0].numel() < need or ent[1].numel() < ncnt:
-        ws = torch.empty(max(need, ent[0].numel() if ent else 0, 64 << 20), device="cuda", dtype=torch.uint8)
-        cnt = torch.zeros(max(ncnt, ent[1].numel() if ent else 0, 4096), device="cuda", dtype=torch.int32)
+        floor = 0 if table is _FIX_CAPTURE else 64 << 20
+        ws = torch.empty(max(need, ent[0].numel() if ent else 0, floor), device="cuda", dtype=torch.uint8)
+        cnt = torch.empty(max(ncnt, ent[1].numel() if ent else 0, 4096), device="cuda", dtype=torch.int32)
+        call("vacnic_zero_bytes", cnt.data_ptr(), cnt.numel() * 4, stream)
         if ent is not None:
             _FIX_OLD.append(ent)
-        torch.cuda.current_stream().synchronize()      # (rare: first use / growth) the zero fill ran on torch's stream, the launch may not
-        ent = _FIX[stream] = [ws, cnt]
+        ent = table[stream] = [ws, cnt]
     return ent
 
 
@@ -148,7 +155,12 @@ def gemm(x, w, M, N, K, *, bias=None, out=None, ldx=None, ldw=None, ldo=None, x_
                          preact is not None, dact_src is not None, residual is not None))
     if tile_hint == 0 and GEMM_TUNED:
         t = GEMM_TUNED.get(f"{int(x_kstrided)},{int(w_kstrided)},{M},{N},{K},{out_mode},{int(preact is not None)}")
-        if t is not None:
+        if t is not None and len(t) > 4 and t[4]:
+            # measured winner = K slices through the ordered fix-up (long reductions into a small output: too few tiles to fill
+            # 256 CUs unsplit, and a bf16 / activation / residual epilogue cannot meet in atomics)
+            if _TUNED_FIXUP and split_k == 1:
+                tile_hint, split_k, fixup = t[0], t[1], True
+        elif t is not None:
             tile_hint = t[0] or -1
             if out_mode == 2:
                 split_k = t[1] if _SPLIT_SCALE == 1.0 else max(1, min(32, int(t[1] * _SPLIT_SCALE)))

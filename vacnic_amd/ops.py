@@ -266,13 +266,27 @@ def _wgrad(dy2d, x2d, spec, M):
     streams.keep(dy2d, x2d)                                # alive until the compute stream joins the side stream
 
 
+# split-K weight gradients through the GEMM's ordered fix-up instead of fp32 atomics (bitwise reproducible dW):
+#   0 = atomics (rounds 1-3); 1 = fix-up with the same 128 x 128 tiles and split factors; 2 = fix-up, 256 x 256 tiles x 4 slices for
+#   outputs larger than 1024 x 1024 (the isolated winners of profiles/r4_gemm_fixup_vs_shipped.txt)
+WGRAD_FIXUP = int(__import__("os").environ.get("VACNIC_WGRAD_FIXUP", "0"))
+
+
 def _wgrad_impl(dy2d, x2d, spec, M):
     if spec.wgrad is not None and not _NO_XSUM:
         N, Kd = spec.N, spec.K
         tiles = ((N + 127) // 128) * ((Kd + 127) // 128)
+        split = K.wgrad_split(M, tiles)
+        if WGRAD_FIXUP and split > 1 and M >= 4096:
+            hint = 128
+            if WGRAD_FIXUP == 2:
+                hint, split = (128, 8) if N * Kd <= (1 << 20) else (256, 4)
+            K.gemm(dy2d, x2d, N, Kd, M, out=spec.wgrad, ldx=dy2d.stride(0), ldw=x2d.stride(0), ldo=spec.wgrad.stride(0),
+                   x_kstrided=True, w_kstrided=True, out_mode=2, split_k=split, xsum=spec.bgrad, fixup=True, tile_hint=hint)
+            return
         # the bias gradient (column sums of dY) rides on the weight-gradient GEMM's own dY fragments (xsum): no second pass
         K.gemm(dy2d, x2d, N, Kd, M, out=spec.wgrad, ldx=dy2d.stride(0), ldw=x2d.stride(0), ldo=spec.wgrad.stride(0),
-               x_kstrided=True, w_kstrided=True, out_mode=2, split_k=K.wgrad_split(M, tiles), xsum=spec.bgrad)
+               x_kstrided=True, w_kstrided=True, out_mode=2, split_k=split, xsum=spec.bgrad)
     else:
         if spec.wgrad is not None:                  # A/B: VACNIC_NO_XSUM=1 restores the separate bias-gradient reduction
             N, Kd = spec.N, spec.K
