@@ -523,15 +523,21 @@ def _nbest_mismatch(got, want, lp, max_length, tol=0.5):
     return None
 
 
+def _nbest_dev(got, want, lp):
+    """largest |sum of log-probabilities - reference| over the ranks of an n-best list."""
+    return max(abs(sc * len(ids) ** lp - b) for (sc, ids), (b, _) in zip(got, want))
+
+
 def test_config5_sensitive_fixture_all_beams_and_mutations(monkeypatch):
     """Is the configs[4] fixture able to catch a fault?  Variant m4 of oracle/cfg5_fixture.py plants every token with a margin of
     only 4 .. 7 logit units (bf16 noise < 0.5), EOS 1.5 over the chain, and an n-gram trap that only the no-repeat-3-gram ban
     keeps the caption out of; the golden holds the reference's best sequence AND its five final beams with their scores.
       1. the healthy decoder (persistent step kernel, device beams; host scorer; hipGraph replay) reproduces the best ids of all
          four cases exactly and the whole n-best list (ids + scores of all five beams);
-      2. MUTATIONS must be caught: (a) one corrupted KV-cache position, (b) beam reorders skipped (caches no longer follow their
-         beams), (c) the n-gram bans dropped — each changes the generated ids or the n-best list, (c) into exactly the sequence the
-         REFERENCE generates without the ban."""
+      2. MUTATIONS must be caught: (a) a corrupted KV cache — ONE position negated moves the beams' scores by more than twice what
+         bf16 arithmetic does, one beam's whole ROW negated changes the generated ids; (b) beam reorders skipped (caches no longer
+         follow their beams): the n-best list changes; (c) the n-gram bans dropped: the caption walks into the trap, like the
+         REFERENCE without the ban."""
     from oracle import cfg5_fixture as F5
     from vacnic_amd import generate as Gn, kernels as K, synthetic
     from vacnic_amd.config import ClipVisionConfig
@@ -558,6 +564,7 @@ def test_config5_sensitive_fixture_all_beams_and_mutations(monkeypatch):
                               image_features=img.cuda(), face_features=dev["face_emb"], face_mask=K.face_mask(dev["face_emb"]),
                               name_ids=dev["names_art_ids"], name_mask=nmask, add_ner_ffn=True, return_nbest=True, **extra, **kw)
     cases = dict(F5.CASES)
+    healthy_dev = 0.0
     # ---- 1. healthy: every case, all five beams; eager, graph capture + replay, host-side scorer
     for name, extra in F5.CASES:
         want, want_nb = torch.from_numpy(gold[name]), _ref_nbest(gold, name, LP)
@@ -566,6 +573,8 @@ def test_config5_sensitive_fixture_all_beams_and_mutations(monkeypatch):
             assert torch.equal(got.cpu(), want), (name, leg, got.tolist(), want.tolist())
             bad = _nbest_mismatch(nbest[0], want_nb, LP, ML)
             assert bad is None, (name, leg, bad, [(round(s * len(i) ** LP, 3), len(i)) for s, i in nbest[0]], [(round(s, 3), len(i)) for s, i in want_nb])
+            healthy_dev = max(healthy_dev, _nbest_dev(nbest[0], want_nb, LP))
+    assert healthy_dev <= 0.25, ("bf16 against the fp32 reference: sums of 49 log-probabilities", healthy_dev)
     assert any(s_.graphs for s_ in model._decode_sessions.values()), "graph replay path was not exercised"
     name = "hub_full50"
     want, want_nb = torch.from_numpy(gold[name]), _ref_nbest(gold, name, LP)
@@ -575,18 +584,28 @@ def test_config5_sensitive_fixture_all_beams_and_mutations(monkeypatch):
         got, nbest = run(cases[name], use_graphs=False, **kw)
         return got.cpu(), nbest[0]
 
-    # ---- 2a. one KV-cache position corrupted (keys and values of position 5, every layer, negated from position 20 on)
+    # ---- 2a. KV cache corrupted from position 20 on: (i) keys and values of ONE position (5, every layer and beam) negated,
+    #          (ii) one beam's whole ROW (beam 0 = the best beam, every layer and filled position) overwritten with -4 x itself
     orig_step = Gn.CachedDecoder.step
-
-    def step_corrupt(self, ids_t, t):
-        if t == 20:
-            self.cache_at(t)[:, :, 5, :].neg_()
-        return orig_step(self, ids_t, t)
-    for kw in ({}, {"device_beams": False}):
-        monkeypatch.setattr(Gn.CachedDecoder, "step", step_corrupt)
-        got, nb = mutated(**kw)
-        monkeypatch.setattr(Gn.CachedDecoder, "step", orig_step)
-        assert not torch.equal(got, want) or _nbest_mismatch(nb, want_nb, LP, ML) is not None, ("a corrupted KV-cache position went unnoticed", kw)
+    floor = 2.0 * max(healthy_dev, 0.1)
+    for what in ("position", "row"):
+        def step_corrupt(self, ids_t, t, what=what):
+            if t == 20:
+                c = self.cache_at(t)
+                if what == "position":
+                    c[:, :, 5, :].neg_()
+                else:
+                    c[:, 0, :t, :].mul_(-4.0)                      # the best beam's row, every layer: garbage of the wrong sign and scale
+            return orig_step(self, ids_t, t)
+        for kw in ({}, {"device_beams": False}):
+            monkeypatch.setattr(Gn.CachedDecoder, "step", step_corrupt)
+            got, nb = mutated(**kw)
+            monkeypatch.setattr(Gn.CachedDecoder, "step", orig_step)
+            dev_ = _nbest_dev(nb, want_nb, LP) if len(nb) == len(want_nb) else float("inf")
+            if what == "position":
+                assert not torch.equal(got, want) or dev_ > floor, ("one corrupted KV-cache position went unnoticed", kw, dev_, healthy_dev)
+            else:
+                assert not torch.equal(got, want), ("a corrupted KV-cache row did not change the ids", kw, dev_)
     # ---- 2b. the caches stop following their beams (identity permutation instead of the beam indices)
     orig_reorder = Gn.CachedDecoder.reorder
 

@@ -269,7 +269,9 @@ def _wgrad(dy2d, x2d, spec, M):
 # split-K weight gradients through the GEMM's ordered fix-up instead of fp32 atomics (bitwise reproducible dW):
 #   0 = atomics (rounds 1-3); 1 = fix-up with the same 128 x 128 tiles and split factors; 2 = fix-up, 256 x 256 tiles x 4 slices for
 #   outputs larger than 1024 x 1024 (the isolated winners of profiles/r4_gemm_fixup_vs_shipped.txt)
-WGRAD_FIXUP = int(__import__("os").environ.get("VACNIC_WGRAD_FIXUP", "0"))
+# Default 2: same-box A/B 66.79 vs 67.16 ms/step (4 of 4 interleaved runs, profiles/r4_step_ab_fixup.txt) — and with it no weight
+# gradient is summed through atomics any more (the decoder-sized ones go through the grouped kernel): dW is bitwise reproducible.
+WGRAD_FIXUP = int(__import__("os").environ.get("VACNIC_WGRAD_FIXUP", "2"))
 
 
 def _wgrad_impl(dy2d, x2d, spec, M):
@@ -279,7 +281,7 @@ def _wgrad_impl(dy2d, x2d, spec, M):
         split = K.wgrad_split(M, tiles)
         if WGRAD_FIXUP and split > 1 and M >= 4096:
             hint = 128
-            if WGRAD_FIXUP == 2:
+            if WGRAD_FIXUP == 2 and N >= 512 and Kd >= 512:
                 hint, split = (128, 8) if N * Kd <= (1 << 20) else (256, 4)
             K.gemm(dy2d, x2d, N, Kd, M, out=spec.wgrad, ldx=dy2d.stride(0), ldw=x2d.stride(0), ldo=spec.wgrad.stride(0),
                    x_kstrided=True, w_kstrided=True, out_mode=2, split_k=split, xsum=spec.bgrad, fixup=True, tile_hint=hint)
