@@ -54,6 +54,11 @@ PLANTED_M4 = os.path.join(ROOT, "tests", "golden", "cfg5_planted_m4.npz")
 # the sensitive variant: margins, the n-gram trap of path H (positions of the first / second occurrence of the bigram)
 M4_MARGIN, M4_EOS_OVER, M4_TRAP_OVER = 4.0, 1.5, 2.0
 TRAP_I, TRAP_J = 10, 30
+# ... and a DECOY on path P: at position DECOY_T a token that occurs nowhere else beats the chain's token by DECOY_OVER, so for one
+# step the chain is beam 1; the decoy's continuation is a flat field, the chain's is planted, and at the next step the chain is
+# beam 0 again — a beam SWAP (reorder indices [1, 0, ...]): the KV cache of the best hypothesis has to move between rows.  Without
+# it every runner-up of this fixture branches off beam 0 and a decoder that never reordered its caches would go unnoticed.
+DECOY_T, M4_DECOY_OVER = 36, 2.0
 
 
 def m4_margin(t):
@@ -159,8 +164,12 @@ def plant_m4():
     Hc[TRAP_J], Hc[TRAP_J + 1] = Hc[TRAP_I], Hc[TRAP_I + 1]                       # the bigram (a, b) returns
     trap_tok, trap_t = Hc[TRAP_I + 2], TRAP_J + 2                                   # c: banned at position TRAP_J + 2 by no_repeat_ngram_size 3
     assert len(set(Hc[2:])) == len(Hc[2:]) - 2 and Hc[trap_t] != trap_tok
-    ids = sorted(set(chains["P"][1:] + Hc[2:]) | {2})
+    decoy_tok = pool[200]
+    assert decoy_tok not in chains["P"] and decoy_tok not in Hc
+    ids = sorted(set(chains["P"][1:] + Hc[2:]) | {2, decoy_tok})
     NEG = -1e30
+
+    decoy_over = [None]
 
     def sweep(write):
         sd["model.shared.weight"] = E
@@ -176,8 +185,12 @@ def plant_m4():
                 want = seq[t]
                 eos_step = name == "P" and t == T_EOS
                 trap_step = name == "H" and t == trap_t
+                decoy_step = name == "P" and t == DECOY_T
                 others = logits.clone()
                 others[want] = NEG
+                if decoy_step:
+                    others[decoy_tok] = NEG
+                    decoy_over[0] = float(logits[decoy_tok] - logits[want])
                 if eos_step:
                     others[2] = NEG
                     eos_over = float(logits[2] - logits[want])
@@ -192,6 +205,8 @@ def plant_m4():
                         eos_row = E[2] + d * ((target + M4_EOS_OVER - float(logits[2])) / c)
                     if trap_step:
                         E[trap_tok] = E[trap_tok] + d * ((target + M4_TRAP_OVER - float(logits[trap_tok])) / c)
+                    if decoy_step:
+                        E[decoy_tok] = E[decoy_tok] + d * ((target + M4_DECOY_OVER - float(logits[decoy_tok])) / c)
         return worst, eos_over, trap_over, eos_row
 
     with torch.no_grad():
@@ -204,13 +219,16 @@ def plant_m4():
             E[2] = eos_row
             worst, eos_over, trap_over, _ = sweep(False)
             print(f"round {rnd}: smallest chain margin (minus its position's spread) {worst:.3f}, EOS over the chain token {eos_over:.3f}, "
-                  f"trap token over the chain token {trap_over:.3f}", flush=True)
-            if worst >= M4_MARGIN - 0.1 and abs(eos_over - M4_EOS_OVER) <= 0.1 and abs(trap_over - M4_TRAP_OVER) <= 0.1:
+                  f"trap token over the chain token {trap_over:.3f}, decoy over the chain token {decoy_over[0]:.3f}", flush=True)
+            if (worst >= M4_MARGIN - 0.1 and abs(eos_over - M4_EOS_OVER) <= 0.1 and abs(trap_over - M4_TRAP_OVER) <= 0.1
+                    and abs(decoy_over[0] - M4_DECOY_OVER) <= 0.1):
                 break
         assert worst >= M4_MARGIN - 0.25 and abs(eos_over - M4_EOS_OVER) <= 0.25 and abs(trap_over - M4_TRAP_OVER) <= 0.25, (worst, eos_over, trap_over)
+        assert abs(decoy_over[0] - M4_DECOY_OVER) <= 0.25, decoy_over
     planted = {"ids": np.array(ids, dtype=np.int64), "rows": E[torch.tensor(ids)].numpy().astype(np.float32),
                "path_P": np.array(chains["P"], dtype=np.int64), "path_H": np.array(chains["H"], dtype=np.int64),
-               "trap": np.array([TRAP_I, TRAP_J, trap_t, trap_tok], dtype=np.int64)}
+               "trap": np.array([TRAP_I, TRAP_J, trap_t, trap_tok], dtype=np.int64),
+               "decoy": np.array([DECOY_T, decoy_tok], dtype=np.int64)}
     sdf = state_dict(cfg, planted)
     out = O.beam_search_decode(sdf, cfg, src, mask, img, NUM_BEAMS, MAX_LENGTH, LENGTH_PENALTY, forced_eos_token_id=2, **kw)
     planted["plain_ends_early"] = np.array(out.shape[1] == T_EOS + 1)

@@ -579,9 +579,9 @@ def test_config5_sensitive_fixture_all_beams_and_mutations(monkeypatch):
     name = "hub_full50"
     want, want_nb = torch.from_numpy(gold[name]), _ref_nbest(gold, name, LP)
 
-    def mutated(**kw):
+    def mutated(case=name, **kw):
         model.__dict__.pop("_decode_sessions", None)               # fresh sessions: eager positions, so the patched methods run
-        got, nbest = run(cases[name], use_graphs=False, **kw)
+        got, nbest = run(cases[case], use_graphs=False, **kw)
         return got.cpu(), nbest[0]
 
     # ---- 2a. KV cache corrupted from position 20 on: (i) keys and values of ONE position (5, every layer and beam) negated,
@@ -606,16 +606,26 @@ def test_config5_sensitive_fixture_all_beams_and_mutations(monkeypatch):
                 assert not torch.equal(got, want) or dev_ > floor, ("one corrupted KV-cache position went unnoticed", kw, dev_, healthy_dev)
             else:
                 assert not torch.equal(got, want), ("a corrupted KV-cache row did not change the ids", kw, dev_)
-    # ---- 2b. the caches stop following their beams (identity permutation instead of the beam indices)
+    # ---- 2b. the caches stop following their beams (identity permutation instead of the beam indices).  Path P carries the decoy:
+    #          for one step the chain is beam 1 and then moves back to row 0 — its cache has to move with it
     orig_reorder = Gn.CachedDecoder.reorder
+    swaps = []
 
     def reorder_skip(self, beam_idx, t):
+        swaps.append(beam_idx.tolist())
         return orig_reorder(self, torch.arange(beam_idx.numel(), device=beam_idx.device, dtype=beam_idx.dtype), t)
+    want_p, want_nb_p = torch.from_numpy(gold["full50"]), _ref_nbest(gold, "full50", LP)
     monkeypatch.setattr(Gn.CachedDecoder, "reorder", reorder_skip)
-    got, nb = mutated()
+    got, nb = mutated("full50", device_beams=False)                # (host-side scorer: the reorder indices are visible to the test)
     monkeypatch.setattr(Gn.CachedDecoder, "reorder", orig_reorder)
-    bad = _nbest_mismatch(nb, want_nb, LP, ML)
-    assert not torch.equal(got, want) or bad is not None, "skipped beam reorders went unnoticed (best beam AND n-best list unchanged)"
+    assert any(s_[0] != 0 for s_ in swaps), "the fixture must make the best hypothesis change rows at least once (decoy)"
+    dev_ = _nbest_dev(nb, want_nb_p, LP) if len(nb) == len(want_nb_p) else float("inf")
+    assert not torch.equal(got, want_p) or dev_ > floor, ("skipped beam reorders went unnoticed", dev_, healthy_dev)
+    monkeypatch.setattr(Gn.CachedDecoder, "reorder", lambda self, beam_idx, t: orig_reorder(self, torch.arange(beam_idx.numel(), device=beam_idx.device, dtype=beam_idx.dtype), t))
+    got, nb = mutated("full50")                                    # ... and on the device-beam path
+    monkeypatch.setattr(Gn.CachedDecoder, "reorder", orig_reorder)
+    dev_ = _nbest_dev(nb, want_nb_p, LP) if len(nb) == len(want_nb_p) else float("inf")
+    assert not torch.equal(got, want_p) or dev_ > floor, ("skipped beam reorders went unnoticed (device beams)", dev_, healthy_dev)
     # ---- 2c. the n-gram bans dropped: the caption walks into the trap, exactly as the reference does without the ban
     orig_body = Gn.DecodeSession.body
 
