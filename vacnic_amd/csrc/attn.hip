@@ -153,13 +153,20 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const bf16_t* base, 
   return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
 }
 
-// per-key additive bias for the whole key range, in LDS: 0 / FMIN (masked) / -inf (padding)
-__device__ __forceinline__ void fill_key_bias(float* kbias, const uint8_t* mask_row, int Tk, int Tk_pad) {
+// per-key additive bias for the whole key range, in LDS: 0 / FMIN (masked) / -inf (padding), and one word per 64-key tile:
+// nonzero when any key of the tile carries a bias.  A tile without one (the common case: most of a padded batch, all of a full
+// one) takes the PLAIN softmax path — no bias load / add, the row maximum taken on the raw scores (scale > 0), the subtraction of
+// the maximum folded into the scaling FMA: fma + exp2 + add per probability instead of fma + sub + exp2 + add.  The softmax
+// loops of these kernels are VALU-bound (forward: 193 vector instructions + 33 exp2 against 16 MFMAs per tile and wave).
+// (keys j = tid + 256 i: the 64 lanes of a wave cover exactly tile 4 i + wave, so its flag is one ballot, no atomics)
+__device__ __forceinline__ void fill_key_bias(float* kbias, unsigned* dirty, const uint8_t* mask_row, int Tk, int Tk_pad) {
   for (int j = threadIdx.x; j < Tk_pad; j += 256) {
     float b = 0.f;
     if (j >= Tk) b = -INFINITY;
     else if (mask_row && mask_row[j] == 0) b = FMIN;
     kbias[j] = b;
+    const unsigned long long any = __builtin_amdgcn_ballot_w64(b != 0.f);
+    if ((threadIdx.x & 63) == 0) dirty[j >> 6] = any != 0ull;
   }
 }
 
@@ -190,6 +197,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   const int ql = lane & 31, hh = lane >> 5;
   const int Tk_pad = (p.Tk + 63) & ~63;
   float* kbias = (float*)(smem + 4 * TILE_B);
+  unsigned* dirty = (unsigned*)(kbias + Tk_pad);
 
   const bf16_t* qb = p.q + (long)b * p.bsq + hd * 64;
   const bf16_t* kb = p.k + (long)b * p.bsk + hd * 64;
@@ -203,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
 
   stage64(ks, smem, 0, p.Tk, p.ldk, wave, lane);
   stage64(vs, smem + TILE_B, 0, p.Tk, p.ldv, wave, lane);
-  fill_key_bias(kbias, p.key_mask ? p.key_mask + (long)b * p.Tk : nullptr, p.Tk, Tk_pad);
+  fill_key_bias(kbias, dirty, p.key_mask ? p.key_mask + (long)b * p.Tk : nullptr, p.Tk, Tk_pad);
   // scores live in the log2 domain (v_exp_f32 is 2^x): scale*log2(e) folded into one FMA per score, masks as -FLT_MAX (they
   // absorb any finite score exactly like the reference's additive finfo.min, and two of them overflow to -inf like there)
   const float scale2 = p.scale * 1.4426950408889634f;
@@ -247,37 +255,57 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
       for (int ks4 = 0; ks4 < 4; ++ks4)
         s[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(kt, kb2 * 32, ks4, lane), qf[ks4], s[kb2], 0, 0, 0);
     }
-    // ---- scale + masks, tile max
-    float tmax = -INFINITY;
+    // ---- scale + masks, tile max, probabilities
+    float tmax = -INFINITY, psum = 0.f, alpha;
+    if (!CAUSAL && __builtin_amdgcn_readfirstlane((int)dirty[t]) == 0) {
+      // plain tile (fill_key_bias): maximum on the raw scores, then one FMA + exp2 per probability
 #pragma unroll
-    for (int kb2 = 0; kb2 < 2; ++kb2) {
+      for (int kb2 = 0; kb2 < 2; ++kb2)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int kbase = t * 64 + kb2 * 32 + 8 * g + 4 * hh;
-        const f32x4 bias = *(const f32x4*)(kbias + kbase);
+        for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[kb2][r]);
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float m_new = fmaxf(m_run, tmax * scale2);
+      alpha = __builtin_amdgcn_exp2f(m_run - m_new);             // m_run = -inf on the first tile -> 0
+      const float nm = -m_new;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float v = fmaf(s[kb2][4 * g + e], scale2, bias[e]);
-          if (CAUSAL && (kbase + e) > qidx) v += FMIN;
-          s[kb2][4 * g + e] = v;
-          tmax = fmaxf(tmax, v);
+      for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float e = __builtin_amdgcn_exp2f(fmaf(s[kb2][r], scale2, nm));
+          s[kb2][r] = e;
+          psum += e;
+        }
+      m_run = m_new;
+    } else {
+#pragma unroll
+      for (int kb2 = 0; kb2 < 2; ++kb2) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int kbase = t * 64 + kb2 * 32 + 8 * g + 4 * hh;
+          const f32x4 bias = *(const f32x4*)(kbias + kbase);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = fmaf(s[kb2][4 * g + e], scale2, bias[e]);
+            if (CAUSAL && (kbase + e) > qidx) v += FMIN;
+            s[kb2][4 * g + e] = v;
+            tmax = fmaxf(tmax, v);
+          }
         }
       }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float m_new = fmaxf(m_run, tmax);
+      alpha = __builtin_amdgcn_exp2f(m_run - m_new);             // m_run = -inf on the first tile -> 0
+#pragma unroll
+      for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float e = __builtin_amdgcn_exp2f(s[kb2][r] - m_new);
+          s[kb2][r] = e;
+          psum += e;
+        }
+      m_run = m_new;
     }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float m_new = fmaxf(m_run, tmax);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // m_run = -inf on the first tile -> 0
-    float psum = 0.f;
-#pragma unroll
-    for (int kb2 = 0; kb2 < 2; ++kb2)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(s[kb2][r] - m_new);
-        s[kb2][r] = e;
-        psum += e;
-      }
     l_run = l_run * alpha + psum;
-    m_run = m_new;
     if (DROP) {          // the normaliser sums the undropped probabilities (softmax first, dropout second: MFULL:534,546)
 #pragma unroll
       for (int kb2 = 0; kb2 < 2; ++kb2) {
@@ -377,8 +405,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnP p) {
   const int k0 = kblk * 128 + wave * 32;
   const int kl = lane & 31, hh = lane >> 5;
   const int kidx = k0 + kl;
-  // LDS: 2 x {Q tile, dO tile} + 2 x {lse[64], delta[64]}
+  // LDS: 2 x {Q tile, dO tile} + 2 x {lse[64], delta[64], -lse log2(e) [64]}
   float* stats = (float*)(smem + 4 * TILE_B);
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float scale2 = p.scale * LOG2E;
 
   const bf16_t* qb = p.q + (long)b * p.bsq + hd * 64;
   const bf16_t* kb = p.k + (long)b * p.bsk + hd * 64;
@@ -420,12 +450,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnP p) {
     }
     return v;
   };
+  auto put_stat = [&](float* st, float sv) {
+    if (tid < 128) st[tid] = sv;
+    if (tid < 64) st[128 + tid] = -sv * LOG2E;       // (padding queries: lse = +inf -> -inf -> probability 0 on the plain path too)
+  };
+  // every key of this wave unmasked and in range, no causal mask: the plain path (see fill_key_bias) for every tile
+  const bool plain = !p.causal && __builtin_amdgcn_ballot_w64(kbias != 0.f) == 0ull;
 
   if (t_begin < nq_tiles) {
     const float sv = load_stat(t_begin);
     stage64(qs, smem, t_begin * 64, p.Tq, p.ldq, wave, lane);
     stage64(dos, smem + TILE_B, t_begin * 64, p.Tq, p.ldo, wave, lane);
-    if (tid < 128) stats[tid] = sv;
+    put_stat(stats, sv);
   }
   for (int t = t_begin; t < nq_tiles; ++t) {
     const int cur = (t - t_begin) & 1;
@@ -436,13 +472,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnP p) {
       const float sv = load_stat(t + 1);
       stage64(qs, nq, (t + 1) * 64, p.Tq, p.ldq, wave, lane);
       stage64(dos, nq + TILE_B, (t + 1) * 64, p.Tq, p.ldo, wave, lane);
-      if (tid < 128) stats[(cur ^ 1) * 128 + tid] = sv;
+      put_stat(stats + (cur ^ 1) * 192, sv);
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     lds_barrier();
-    const float* st = stats + cur * 128;
+    const float* st = stats + cur * 192;
 
 #pragma unroll
     for (int qb2 = 0; qb2 < 2; ++qb2) {
@@ -461,13 +497,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnP p) {
         const f32x4 d4 = *(const f32x4*)(st + 64 + ql0);
         float mq[4] = {1.f, 1.f, 1.f, 1.f};
         if (DROP) drop_word_factors(dctx, mb[g], mq);
+        // (dS carries no softmax scale here: dK = scale * dS^T Q is scaled once, on the way out)
+        if (plain) {
+          const f32x4 nl4 = *(const f32x4*)(st + 128 + ql0);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float v = s[4 * g + e] * p.scale + kbias;
-          if (p.causal && kidx > (t * 64 + ql0 + e)) v += FMIN;
-          const float pe = __expf(v - l4[e]);
-          s[4 * g + e] = DROP ? pe * mq[e] : pe;                                   // dV = (P o M)^T dO
-          dp[4 * g + e] = pe * ((DROP ? dp[4 * g + e] * mq[e] : dp[4 * g + e]) - d4[e]) * p.scale;    // dS = P o (dP o M - delta)
+          for (int e = 0; e < 4; ++e) {
+            const float pe = __builtin_amdgcn_exp2f(fmaf(s[4 * g + e], scale2, nl4[e]));
+            s[4 * g + e] = DROP ? pe * mq[e] : pe;                                   // dV = (P o M)^T dO
+            dp[4 * g + e] = pe * ((DROP ? dp[4 * g + e] * mq[e] : dp[4 * g + e]) - d4[e]);    // dS = P o (dP o M - delta)
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = s[4 * g + e] * p.scale + kbias;
+            if (p.causal && kidx > (t * 64 + ql0 + e)) v += FMIN;
+            const float pe = __expf(v - l4[e]);
+            s[4 * g + e] = DROP ? pe * mq[e] : pe;
+            dp[4 * g + e] = pe * ((DROP ? dp[4 * g + e] * mq[e] : dp[4 * g + e]) - d4[e]);
+          }
         }
       }
 #pragma unroll
@@ -490,7 +537,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnP p) {
     for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        u32x2 a = {pack2bf(dk[hb][4 * g], dk[hb][4 * g + 1]), pack2bf(dk[hb][4 * g + 2], dk[hb][4 * g + 3])};
+        u32x2 a = {pack2bf(dk[hb][4 * g] * p.scale, dk[hb][4 * g + 1] * p.scale), pack2bf(dk[hb][4 * g + 2] * p.scale, dk[hb][4 * g + 3] * p.scale)};
         u32x2 c = {pack2bf(dv[hb][4 * g], dv[hb][4 * g + 1]), pack2bf(dv[hb][4 * g + 2], dv[hb][4 * g + 3])};
         *(u32x2*)(dkrow + hb * 32 + 8 * g + 4 * hh) = a;
         *(u32x2*)(dvrow + hb * 32 + 8 * g + 4 * hh) = c;
@@ -520,6 +567,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
   const int qidx = q0 + ql;
   const int Tk_pad = (p.Tk + 63) & ~63;
   float* kbias = (float*)(smem + 4 * TILE_B);
+  unsigned* dirty = (unsigned*)(kbias + Tk_pad);
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float scale2 = p.scale * LOG2E;
 
   const bf16_t* qb = p.q + (long)b * p.bsq + hd * 64;
   const bf16_t* kb = p.k + (long)b * p.bsk + hd * 64;
@@ -535,7 +585,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
 
   stage64(ks, smem, 0, p.Tk, p.ldk, wave, lane);
   stage64(vs, smem + TILE_B, 0, p.Tk, p.ldv, wave, lane);
-  fill_key_bias(kbias, p.key_mask ? p.key_mask + (long)b * p.Tk : nullptr, p.Tk, Tk_pad);
+  fill_key_bias(kbias, dirty, p.key_mask ? p.key_mask + (long)b * p.Tk : nullptr, p.Tk, Tk_pad);
 
   bf16x8 qf[4], dof[4];
 #pragma unroll
@@ -548,6 +598,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
     lse_q = p.lse[((long)b * p.H + hd) * p.Tq + qidx];
     if (!DELTA_PASS) delta_q = p.delta[((long)b * p.H + hd) * p.Tq + qidx];
   }
+  const float nl2 = -lse_q * LOG2E;                    // (padding queries: -inf -> probability 0)
   float dsum = 0.f;
   f32x16 dq[2];
   dq[0] = (f32x16)(0.f); dq[1] = (f32x16)(0.f);
@@ -567,6 +618,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     lds_barrier();
+    const bool plain = !p.causal && __builtin_amdgcn_readfirstlane((int)dirty[t]) == 0;      // see fill_key_bias
 #pragma unroll
     for (int kb2 = 0; kb2 < 2; ++kb2) {
       f32x16 s = (f32x16)(0.f), dp = (f32x16)(0.f);
@@ -577,20 +629,31 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
       }
       uint32_t mw[4];
       if (DROP) drop_block_keys(dctx, qidx, t * 64 + kb2 * 32 + 4 * hh, lane, mw);
+      // (dS carries no softmax scale here: dQ = scale * dS K is scaled once, on the way out)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int kbase = t * 64 + kb2 * 32 + 8 * g + 4 * hh;
-        const f32x4 bias = *(const f32x4*)(kbias + kbase);
         float mk[4] = {1.f, 1.f, 1.f, 1.f};
         if (DROP) drop_word_factors(dctx, mw[g], mk);
+        if (plain) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float v = s[4 * g + e] * p.scale + bias[e];
-          if (p.causal && (kbase + e) > qidx) v += FMIN;
-          const float pe = __expf(v - lse_q);
-          const float dpm = DROP ? dp[4 * g + e] * mk[e] : dp[4 * g + e];
-          if (DELTA_PASS) dsum += pe * dpm;                     // (pe is exactly 0 for padding keys: bias = -inf)
-          else dp[4 * g + e] = pe * (dpm - delta_q) * p.scale;
+          for (int e = 0; e < 4; ++e) {
+            const float pe = __builtin_amdgcn_exp2f(fmaf(s[4 * g + e], scale2, nl2));
+            const float dpm = DROP ? dp[4 * g + e] * mk[e] : dp[4 * g + e];
+            if (DELTA_PASS) dsum += pe * dpm;
+            else dp[4 * g + e] = pe * (dpm - delta_q);
+          }
+        } else {
+          const f32x4 bias = *(const f32x4*)(kbias + kbase);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = s[4 * g + e] * p.scale + bias[e];
+            if (p.causal && (kbase + e) > qidx) v += FMIN;
+            const float pe = __expf(v - lse_q);
+            const float dpm = DROP ? dp[4 * g + e] * mk[e] : dp[4 * g + e];
+            if (DELTA_PASS) dsum += pe * dpm;                     // (pe is exactly 0 for padding keys: bias = -inf)
+            else dp[4 * g + e] = pe * (dpm - delta_q);
+          }
         }
       }
       if (!DELTA_PASS) {
@@ -616,7 +679,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
     for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        u32x2 a = {pack2bf(dq[hb][4 * g], dq[hb][4 * g + 1]), pack2bf(dq[hb][4 * g + 2], dq[hb][4 * g + 3])};
+        u32x2 a = {pack2bf(dq[hb][4 * g] * p.scale, dq[hb][4 * g + 1] * p.scale), pack2bf(dq[hb][4 * g + 2] * p.scale, dq[hb][4 * g + 3] * p.scale)};
         *(u32x2*)(drow + hb * 32 + 8 * g + 4 * hh) = a;
       }
   }
@@ -801,7 +864,7 @@ extern "C" int vacnic_attn_fwd(const vacnic_attn_fwd_args* a, void* stream) {
   }
   const int Tk_pad = (p.Tk + 63) & ~63;
   dim3 grid((unsigned)(((p.Tq + 127) / 128) * p.H * p.B));
-  const size_t lds = 4 * TILE_B + Tk_pad * 4;
+  const size_t lds = 4 * TILE_B + Tk_pad * 4 + (Tk_pad >> 6) * 4;          // K/V ring + key bias + per-tile flags
   hipStream_t st = (hipStream_t)stream;
   if (p.drop_thr) {
     if (p.causal) hipLaunchKernelGGL((attn_fwd_kernel<true, true>), grid, dim3(256), lds, st, p);
@@ -837,7 +900,7 @@ extern "C" int vacnic_attn_bwd(const vacnic_attn_bwd_args* a, void* stream) {
   const long rows = (long)p.B * p.Tq;
   const int Tk_pad = (p.Tk + 63) & ~63;
   const dim3 gkv((unsigned)(((p.Tk + 127) / 128) * p.H * p.B)), gq((unsigned)(((p.Tq + 127) / 128) * p.H * p.B));
-  const size_t lds_q = 4 * TILE_B + Tk_pad * 4;
+  const size_t lds_q = 4 * TILE_B + Tk_pad * 4 + (Tk_pad >> 6) * 4;
   p.delta_out = a->delta;
   // delta: from the kernels' own P and dP (a sweep of the dQ kernel without its last product) for the decoder-sized problems,
   // where it costs microseconds; rowsum(dO o O) for the long encoder sequences (a_delta_mode: 0 = by size, 1 = always the sweep,
@@ -853,8 +916,8 @@ extern "C" int vacnic_attn_bwd(const vacnic_attn_bwd_args* a, void* stream) {
                        (const bf16_t*)a->dout, a->delta, p.B, p.H, p.Tq, p.ldo, (long)p.bso);
   }
   VLAUNCH_CHECK();
-  if (p.drop_thr) hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, gkv, dim3(256), 4 * TILE_B + 2 * 128 * 4, s, p);
-  else hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, gkv, dim3(256), 4 * TILE_B + 2 * 128 * 4, s, p);
+  if (p.drop_thr) hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, gkv, dim3(256), 4 * TILE_B + 2 * 192 * 4, s, p);
+  else hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, gkv, dim3(256), 4 * TILE_B + 2 * 192 * 4, s, p);
   VLAUNCH_CHECK();
   if (p.drop_thr) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, false>), gq, dim3(256), lds_q, s, p);
   else hipLaunchKernelGGL((attn_bwd_dq_kernel<false, false>), gq, dim3(256), lds_q, s, p);

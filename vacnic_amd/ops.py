@@ -668,6 +668,10 @@ class EmbedLnFn(Function):
     def backward(ctx, dout):
         ids, mean, rstd = ctx.saved_tensors
         tok, pos, gamma, beta, scale, p, seed, pad = ctx.args
+        if streams.explicit() and streams.wgrad_stream() is not None:
+            # the tied matrix has another writer on the weight-gradient stream (the LM head's dE GEMMs: plain read-modify-write of
+            # the same rows this kernel adds to with atomics): order behind it
+            K.fence(streams.wgrad_raw(), K._stream())
         K.embed_ln_bwd(ids, tok.w16, pos.w16, _c(dout), gamma, mean, rstd, tok.grad, pos.grad, gamma.grad, beta.grad,
                        embed_scale=scale, padding_idx=pad, p_drop=p, seed=seed, seed_dev=Rng.device_counter() if p > 0 else None)
         ddp.done(tok.grad, pos.grad, gamma.grad, beta.grad)
@@ -786,11 +790,18 @@ class LmHeadCeFn(Function):
         emb16_pad, egrad, V, ignore_index, R, d, hshape = ctx.misc
         rowp = K.lmhead_ce_rowp(row_lse, tgt, acc, grad_out=_c(g), grad_scale=1.0, ignore_index=ignore_index)
         CH = min(LMHEAD_CHUNK, (V + 7) // 8 * 8)
-        dl = torch.empty((R, CH), device=h2.device, dtype=BF16)
+        # dE (the tied matrix's weight gradient) is needed only by AdamW / the reducer: with side streams on it runs on the
+        # weight-gradient stream beside the next chunk's dlogits / dh GEMMs, out of the decoder phase's chain (the least busy part of
+        # the step).  Two dlogits buffers alternate; a chunk's buffer is reused only after the side stream has read it.
+        side = streams.wgrad_stream() if (egrad is not None and streams.explicit()) else None
+        dls = [torch.empty((R, CH), device=h2.device, dtype=BF16) for _ in range(2 if side is not None else 1)]
         dh32 = K.zero_(torch.empty((R, d), device=h2.device, dtype=torch.float32))
-        for c0 in range(0, V, CH):
+        for ci, c0 in enumerate(range(0, V, CH)):
             n = min(CH, V - c0)
             n8 = (n + 7) // 8 * 8                                  # dlogits pad columns are written as zeros; E's pad rows are zero
+            dl = dls[ci % len(dls)]
+            if side is not None and ci >= 2:
+                K.fence(streams.wgrad_raw(), K._stream())          # the dE GEMM of chunk ci - 2 has read this buffer
             K.lmhead_ce_dlogits(h2, emb16_pad, tgt, V, rowp, dl, c0, n, ignore_index=ignore_index)
             ec = emb16_pad[c0:c0 + n8]
             # dh += dlogits_c . E_c: a reduction 8-16x longer than the output is wide -> split-K, fp32 accumulate
@@ -800,8 +811,14 @@ class LmHeadCeFn(Function):
                 K.gemm(dl, ec, R, d, n8, out=dh32, ldx=CH, w_kstrided=True, out_mode=2, split_k=8)
             if egrad is not None:                                  # dE[c0:c0+n] += dlogits_c^T h
                 tiles = ((n + 127) // 128) * ((d + 127) // 128)
-                K.gemm(dl, h2, n, d, R, out=egrad[c0:c0 + n], ldx=CH, ldw=d, ldo=d, x_kstrided=True, w_kstrided=True, out_mode=2,
-                       split_k=K.wgrad_split(R, tiles))
+                if side is not None:
+                    K.fence(K._stream(), streams.wgrad_raw())      # dlogits of this chunk (and h) are ready
+                    with K.launch_on(streams.wgrad_raw(), fence=False):
+                        K.gemm(dl, h2, n, d, R, out=egrad[c0:c0 + n], ldx=CH, ldw=d, ldo=d, x_kstrided=True, w_kstrided=True, out_mode=2,
+                               split_k=K.wgrad_split(R, tiles))
+                else:
+                    K.gemm(dl, h2, n, d, R, out=egrad[c0:c0 + n], ldx=CH, ldw=d, ldo=d, x_kstrided=True, w_kstrided=True, out_mode=2,
+                           split_k=K.wgrad_split(R, tiles))
         dh = K.cast_f32_bf16(dh32)
         ddp.done(egrad)
         return dh.view(hshape), None, None, None, None, None, None, None
