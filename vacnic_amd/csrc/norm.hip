@@ -32,15 +32,20 @@ __device__ __forceinline__ void store8(bf16_t* p, const float v[8]) {
 // keep-scale factors for the 8 elements starting at flat index idx (multiple of 8): ONE Philox4x32-10 block per 8 elements,
 // 16 random bits per element (drop probability quantised to 2^-16) — the LayerNorm backward is VALU-bound on the mask
 // recompute, and 32-bit draws (two blocks per 8 elements) cost it 10 us per 16384x1024 launch.
-__device__ __forceinline__ void drop8(uint64_t seed, uint64_t idx, uint32_t thr, float inv_keep, float m[8]) {
-  uint32_t b[4];
-  dropout_bits4(seed, idx >> 3, b);
-  const uint32_t thr16 = thr >> 16;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    m[2 * i] = (b[i] & 0xffffu) >= thr16 ? inv_keep : 0.f;
-    m[2 * i + 1] = (b[i] >> 16) >= thr16 ? inv_keep : 0.f;
+// Hidden-state dropout of the LayerNorm family (add_ln / embed_ln, forward and backward): p quantised to 1/256 like the other two
+// dropouts; ONE Philox block per lane and PAIR of chunks — chunk i of a lane (columns 8 (lane + 64 i) ..) takes bytes
+// 8 (i & 1) .. of the block (row, lane, i >> 1) — so a 1024-wide row costs every lane one Philox call instead of two (the
+// generator is ~40 quarter-rate integer multiplies a call: it was a third of these kernels' issue time).  Loops over i are
+// unrolled in ascending order, so the block generated for an even i is still in `cache` for i + 1.
+struct HDrop { uint32_t w[4]; };
+__device__ __forceinline__ uint32_t hdrop_threshold(float p) { const uint32_t t = (uint32_t)(p * 256.f + 0.5f); return t > 255u ? 255u : t; }
+__device__ __forceinline__ float hdrop_inv_keep(float p) { return p > 0.f ? 256.f / (256.f - (float)hdrop_threshold(p)) : 1.f; }
+__device__ __forceinline__ void drop8(uint64_t seed, int64_t row, int lane, int i, uint32_t thr8, float inv_keep, float m[8], HDrop& cache) {
+  if ((i & 1) == 0) {
+    const uint64_t blk = (uint64_t)row * 128u + (unsigned)lane + 64u * (unsigned)(i >> 1);
+    philox4x32((uint32_t)blk, (uint32_t)(blk >> 32), 0x4C4E4452u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), cache.w);
   }
+  actdrop_factors8(cache.w[2 * (i & 1)], cache.w[2 * (i & 1) + 1], thr8, inv_keep, m);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -55,8 +60,9 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const bf16_t* __restric
   if (row >= R) return;
   seed = mix_seed(seed, seed_dev);
   const int nchunk = D >> 3;
-  const uint32_t thr = dropout_threshold(p_drop);
-  const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  const uint32_t thr = hdrop_threshold(p_drop);
+  HDrop hd;
+  const float inv_keep = hdrop_inv_keep(p_drop);
   float h[NCH][8];
   float s = 0.f;
 #pragma unroll
@@ -67,7 +73,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const bf16_t* __restric
       load8(x + row * D + c * 8, xv);
       if (p_drop > 0.f) {
         float m[8];
-        drop8(seed, (uint64_t)row * D + c * 8, thr, inv_keep, m);
+        drop8(seed, row, lane, i, thr, inv_keep, m, hd);
 #pragma unroll
         for (int j = 0; j < 8; ++j) xv[j] *= m[j];
       }
@@ -132,15 +138,37 @@ __global__ __launch_bounds__(64 * NW) void add_ln_bwd_kernel(const bf16_t* __res
   const int wave = threadIdx.x >> 6;
   seed = mix_seed(seed, seed_dev);
   const int nchunk = D >> 3;
-  const uint32_t thr = dropout_threshold(p_drop);
-  const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  const uint32_t thr = hdrop_threshold(p_drop);
+  HDrop hd;
+  const float inv_keep = hdrop_inv_keep(p_drop);
   float dg[NCH][8], db[NCH][8];
 #pragma unroll
   for (int i = 0; i < NCH; ++i)
 #pragma unroll
     for (int j = 0; j < 8; ++j) { dg[i][j] = 0.f; db[i][j] = 0.f; }
 
-  for (int64_t row = (int64_t)blockIdx.x * NW + wave; row < R; row += (int64_t)gridDim.x * NW) {
+  // A wave walks its rows one after the other, and a row is two dependent wave reductions behind its loads: the NEXT row's
+  // x / residual / dout chunks are requested before the current row is reduced, so that a memory round trip is always in
+  // flight (the kernel ran at 3.5-4 TB/s with one row per wave in flight).
+  const int64_t rstep = (int64_t)gridDim.x * NW;
+  u32x4 nx[NCH], nr[NCH], nd[NCH];
+  auto fetch = [&](int64_t row) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nchunk && row < R) {
+        nx[i] = *(const u32x4*)(x + row * D + c * 8);
+        if (res) nr[i] = *(const u32x4*)(res + row * D + c * 8);
+        nd[i] = *(const u32x4*)(dout + row * D + c * 8);
+      }
+    }
+  };
+  auto unpack = [](u32x4 r, float v[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(r[i] << 16); v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u); }
+  };
+  fetch((int64_t)blockIdx.x * NW + wave);
+  for (int64_t row = (int64_t)blockIdx.x * NW + wave; row < R; row += rstep) {
     const float mean = mean_i[row], rstd = rstd_i[row];
     float xh[NCH][8], dxh[NCH][8];
     uint32_t keep[NCH];                      // dropout keep bits (one register per chunk instead of 8 scale factors)
@@ -150,10 +178,10 @@ __global__ __launch_bounds__(64 * NW) void add_ln_bwd_kernel(const bf16_t* __res
       const int c = lane + 64 * i;
       if (c < nchunk) {
         float xv[8], dv[8];
-        load8(x + row * D + c * 8, xv);
+        unpack(nx[i], xv);
         if (p_drop > 0.f) {
           float m[8];
-          drop8(seed, (uint64_t)row * D + c * 8, thr, inv_keep, m);
+          drop8(seed, row, lane, i, thr, inv_keep, m, hd);
           uint32_t kb = 0;
 #pragma unroll
           for (int j = 0; j < 8; ++j) { xv[j] *= m[j]; kb |= (m[j] != 0.f ? 1u : 0u) << j; }
@@ -161,11 +189,11 @@ __global__ __launch_bounds__(64 * NW) void add_ln_bwd_kernel(const bf16_t* __res
         }
         if (res) {
           float rv[8];
-          load8(res + row * D + c * 8, rv);
+          unpack(nr[i], rv);
 #pragma unroll
           for (int j = 0; j < 8; ++j) xv[j] += rv[j];
         }
-        load8(dout + row * D + c * 8, dv);
+        unpack(nd[i], dv);
         f32x4 g0 = *(const f32x4*)(gamma + c * 8), g1 = *(const f32x4*)(gamma + c * 8 + 4);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -178,6 +206,7 @@ __global__ __launch_bounds__(64 * NW) void add_ln_bwd_kernel(const bf16_t* __res
         }
       }
     }
+    fetch(row + rstep);                      // (this row's raw chunks are consumed: the next row travels during the reductions)
     s1 = wave_sum(s1) / D; s2 = wave_sum(s2) / D;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
@@ -243,8 +272,9 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* __rest
   int64_t id = ids[row];
   id = id < 0 ? 0 : (id >= V ? V - 1 : id);   // clamp: a bad id must not fault the GPU
   const int t = (int)(row % T) + pos_offset;
-  const uint32_t thr = dropout_threshold(p_drop);
-  const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  const uint32_t thr = hdrop_threshold(p_drop);
+  HDrop hd;
+  const float inv_keep = hdrop_inv_keep(p_drop);
   float h[NCH][8];
   float s = 0.f;
 #pragma unroll
@@ -274,7 +304,7 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* __rest
     const int c = lane + 64 * i;
     if (c < nchunk) {
       float y[8], m[8];
-      if (p_drop > 0.f) drop8(seed, (uint64_t)row * D + c * 8, thr, inv_keep, m);
+      if (p_drop > 0.f) drop8(seed, row, lane, i, thr, inv_keep, m, hd);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         y[j] = (h[i][j] - mean) * rstd * gamma[c * 8 + j] + beta[c * 8 + j];
@@ -303,8 +333,9 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const int64_t* __rest
   const int wave = threadIdx.x >> 6;
   seed = mix_seed(seed, seed_dev);
   const int nchunk = D >> 3;
-  const uint32_t thr = dropout_threshold(p_drop);
-  const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  const uint32_t thr = hdrop_threshold(p_drop);
+  HDrop hd;
+  const float inv_keep = hdrop_inv_keep(p_drop);
   float dg[NCH][8], db[NCH][8];
 #pragma unroll
   for (int i = 0; i < NCH; ++i)
@@ -328,7 +359,7 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const int64_t* __rest
         load8(pos + (int64_t)t * D + c * 8, pv);
         load8(dout + row * D + c * 8, dv);
         if (p_drop > 0.f) {
-          drop8(seed, (uint64_t)row * D + c * 8, thr, inv_keep, m);
+          drop8(seed, row, lane, i, thr, inv_keep, m, hd);
 #pragma unroll
           for (int j = 0; j < 8; ++j) dv[j] *= m[j];
         }
