@@ -576,15 +576,22 @@ def main():
             ach = fl / sec / 1e12
             names = {"NN": "gemm_kernel<false,false> (forward Linear, X[M,K] W[N,K])", "NT": "gemm_kernel<false,true> (dgrad)",
                      "TT": "gemm_kernel<true,true> (wgrad)", "TN": "gemm_kernel<true,false>"}
-            traffic, traffic_src = None, None
-            for prof in ("r3_pmc_hbm_traffic.json", "r2_pmc_hbm_traffic.json"):
-                try:        # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes of this same command
+            traffic, traffic_src, traffic_by_inst = None, None, None
+            for prof in ("r4_pmc_hbm_traffic.json", "r3_pmc_hbm_traffic.json", "r2_pmc_hbm_traffic.json"):
+                try:        # bytes per launch of that kernel class from the committed rocprofv3 --pmc passes of this same command
                     pm = json.load(open(os.path.join(ROOT, "profiles", prof)))["kernels"]
-                    # gemm_kernel<BM, BN, WM, WN, BKT, NSTAGE, PIPE, XKS, WKS, CE>: the last three flags name the layout
-                    tag = {"NN": ", false, false, false>", "NT": ", false, true, false>", "TT": ", true, true, false>", "TN": ", true, false, false>"}[kind]
-                    sel = [v for k, v in pm.items() if "gemm_kernel" in k and tag in k]
+                    # gemm_kernel<BM, BN, WM, WN, BKT, NSTAGE, PIPE, XKS, WKS, CE[, DR]>: template arguments 7 / 8 name the layout
+                    want = {"NN": ("false", "false"), "NT": ("false", "true"), "TT": ("true", "true"), "TN": ("true", "false")}[kind]
+                    sel = {}
+                    for k, v in pm.items():
+                        if "gemm_kernel<" not in k:
+                            continue
+                        targs = [t.strip() for t in k.split("gemm_kernel<", 1)[1].split(">", 1)[0].split(",")]
+                        if len(targs) >= 10 and (targs[7], targs[8]) == want and targs[9] == "false":
+                            sel["gemm_kernel<" + ", ".join(targs) + ">"] = v
                     if sel:
-                        traffic = round(sum(v["launches"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) for v in sel) / sum(v["launches"] for v in sel))
+                        traffic = round(sum(v["launches"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) for v in sel.values()) / sum(v["launches"] for v in sel.values()))
+                        traffic_by_inst = {k: {"launches": v["launches"], "bytes_per_launch": v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]} for k, v in sel.items()}
                         traffic_src = f"committed profile profiles/{prof} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not re-measured in this run)"
                         break
                 except Exception:
@@ -594,7 +601,9 @@ def main():
             alg = sum(r_[5] for r_ in timer.rec if r_[0] == kind) / max(n, 1)
             roof = {"bound": "mfma", "kernel": names[kind], "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                    "traffic_note": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
+                    "traffic_note": "L2 -> fabric bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE; Infinity-Cache hits included: an upper bound on the "
+                                    "HBM bytes), averaged over the launches of this layout class", "traffic_source": traffic_src,
+                    "traffic_by_instantiation": traffic_by_inst,
                     "algorithmic_bytes": round(alg), "traffic_ratio": round(traffic / alg, 3) if traffic and alg else None, "launches": n,
                     "flop_per_launch": round(fl / n),
                     "avg_launch_us": round(sec / n * 1e6, 2),
@@ -610,7 +619,7 @@ def main():
                                       f"224x224 image, {S}-token article, {T}-token caption, per-GPU batch {B}, dropout 0.1, fp32 master + bf16 compute",
                           "global_batch": B * world, "seq_len": S, "caption_len": T, "parallelism": f"dp{world}"},
                "launch_mode": ("hipGraph replay (K-1 steps) + 1 eager instrumented step" if graphed is not None else
-                               f"launch plan replay ({planned.commands} recorded commands, 1 C-ABI call per step; K-1 steps) + 1 eager instrumented step" if planned is not None else
+                               f"launch plan replay ({planned.commands} recorded commands in {len(planned.marks) + 1} segments, one C-ABI call each; K-1 steps) + 1 eager instrumented step" if planned is not None else
                                "eager multi-stream" + (", frozen towers as hipGraph replays" if towers is not None else "")),
                "host_enqueue_ms_per_step": round(host_dt / a.steps * 1e3, 2),
                "c_abi_calls_per_step": round(calls_per_step, 1),

@@ -201,8 +201,14 @@ typedef struct {
   float* partials; int64_t partial_rows;   /* optional caller-owned scratch f32 [partial_rows][2][D] (partial_rows >= min(1024,
                                               ceil(R/4))): dgamma/dbeta are then reduced in two stages (per-block column sums,
                                               one small fold) instead of ~1000 same-address atomics per column */
+  int32_t defer_fold;                      /* 1 (with partials): leave the fold to the caller — vacnic_ln_partial_fold on a stream of
+                                              its choice (the parameter gradients are needed only by AdamW / the reducer, so the fold
+                                              need not sit in the backward chain) */
 } vacnic_add_ln_bwd_args;
 int vacnic_add_ln_bwd(const vacnic_add_ln_bwd_args* a, void* stream);
+/* dgamma[D] += sum over rows of partials[row][0][:], dbeta[D] += ... [row][1][:]  (partials f32 [rows][2][D], as written by
+ * vacnic_add_ln_bwd with defer_fold = 1 for rows = min(1024, ceil(R / 4))) */
+int vacnic_ln_partial_fold(const float* partials, float* dgamma, float* dbeta, int64_t rows, int64_t D, void* stream);
 
 /*
  * out = dropout(LayerNorm(embed[ids]*scale + pos[t + 2]))  — BartEncoder/BartDecoder prologue,

@@ -23,7 +23,7 @@ def timeit(fn, n=20, rounds=5):
 
 def main():
     r = lambda *s: (torch.randn(*s, device="cuda") * 0.5).bfloat16()
-    cases = [("NN", 2048, 1024, 4096, 0), ("NN", 640, 1024, 4096, 0), ("NN", 2048, 1024, 1024, 0), ("NN", 2048, 4096, 1024, 0),
+    cases = [("NN", 16384, 1024, 1024, 0), ("NN", 16384, 4096, 1024, 0), ("NN", 2048, 1024, 4096, 0), ("NN", 640, 1024, 4096, 0), ("NN", 2048, 1024, 1024, 0), ("NN", 2048, 4096, 1024, 0),
              ("NT", 2048, 1024, 4096, 0), ("NT", 2048, 1024, 3072, 0), ("NT", 640, 1024, 4096, 0), ("NT", 2688, 1024, 2048, 0), ("NT", 2048, 1024, 1024, 0),
              ("NT", 4112, 1024, 4096, 0), ("NN", 4112, 1024, 4096, 0), ("NN", 8224, 1024, 4096, 0),
              ("NT", 2048, 1024, 16384, 2),

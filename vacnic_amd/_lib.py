@@ -71,7 +71,8 @@ AddLnFwdArgs = _struct("vacnic_add_ln_fwd_args", [
 AddLnBwdArgs = _struct("vacnic_add_ln_bwd_args", [
     ("dout", vp), ("x", vp), ("residual", vp), ("gamma", vp), ("mean", vp), ("rstd", vp),
     ("dresidual", vp), ("dx", vp), ("dgamma", vp), ("dbeta", vp),
-    ("R", i64), ("D", i64), ("p_drop", f32), ("seed", u64), ("seed_dev", vp), ("partials", vp), ("partial_rows", i64)])
+    ("R", i64), ("D", i64), ("p_drop", f32), ("seed", u64), ("seed_dev", vp), ("partials", vp), ("partial_rows", i64),
+    ("defer_fold", i32)])
 
 EmbedLnFwdArgs = _struct("vacnic_embed_ln_fwd_args", [
     ("ids", vp), ("embed", vp), ("pos", vp), ("gamma", vp), ("beta", vp), ("out", vp), ("mean", vp), ("rstd", vp),
@@ -178,6 +179,7 @@ _PLAIN_FNS = {
     "vacnic_wgrad_group": [C.POINTER(WgradJob), i64, vp],
     "vacnic_plan_end": [i64], "vacnic_plan_replay": [i64, i64, i64], "vacnic_plan_destroy": [i64], "vacnic_stream_fence": [vp, vp],
     "vacnic_plan_pause": [i32],
+    "vacnic_ln_partial_fold": [vp, vp, vp, i64, i64, vp],
     "vacnic_beam_step": [C.POINTER(BeamState), vp, vp, i32, i32, vp],
 }
 EXPORTED = sorted(list(_STRUCT_FNS) + list(_PLAIN_FNS) + ["vacnic_last_error_string", "vacnic_version", "vacnic_decoder_step_sync_bytes", "vacnic_decoder_step_slots_bytes",

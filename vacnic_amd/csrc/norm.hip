@@ -616,13 +616,24 @@ extern "C" int vacnic_add_ln_bwd(const vacnic_add_ln_bwd_args* a, void* stream) 
       case 3: LAUNCH_LN_BWD(3, 4, nb); break;
       default: LAUNCH_LN_BWD(4, 4, nb); break;
     }
-    if (part) {
+    if (a->defer_fold && !part) { vacnic_set_error("add_ln_bwd: defer_fold needs a partials scratch of >= %ld rows and R >= 256", (long)nb); return VACNIC_BAD_SHAPE; }
+    if (part && !a->defer_fold) {
       VLAUNCH_CHECK();
       hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3((unsigned)((2 * a->D + 63) / 64), 8), dim3(256), 0, st, part, a->dgamma,
                          a->dbeta, (int)nb, (int)a->D);
     }
   }
 #undef LAUNCH_LN_BWD
+  VLAUNCH_CHECK();
+  return VACNIC_OK;
+}
+
+extern "C" int vacnic_ln_partial_fold(const float* partials, float* dgamma, float* dbeta, int64_t rows, int64_t D, void* stream) {
+  VPLAN_REC(vacnic_ln_partial_fold, partials, dgamma, dbeta, rows, D, stream);
+  VCHECK(partials && rows > 0 && (dgamma || dbeta), VACNIC_BAD_SHAPE, "ln_partial_fold: null operand");
+  if (int e = check_d(D, "ln_partial_fold")) return e;
+  hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3((unsigned)((2 * D + 63) / 64), 8), dim3(256), 0, (hipStream_t)stream, partials, dgamma,
+                     dbeta, (int)rows, (int)D);
   VLAUNCH_CHECK();
   return VACNIC_OK;
 }

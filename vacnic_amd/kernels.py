@@ -262,7 +262,9 @@ def add_ln_fwd(x, residual, gamma, beta, eps=1e-5, p_drop=0.0, seed=0, need_stat
     return out, mean, rstd
 
 
-def add_ln_bwd(dout, x, residual, gamma, mean, rstd, dgamma, dbeta, p_drop=0.0, seed=0, need_dres=True, seed_dev=None):
+def add_ln_bwd(dout, x, residual, gamma, mean, rstd, dgamma, dbeta, p_drop=0.0, seed=0, need_dres=True, seed_dev=None, fold_on=None):
+    """fold_on: raw stream for the dgamma / dbeta fold of the two-stage reduction (None: in the call, on the launch stream).  The
+    fold is a 5 us kernel nobody in the backward chain waits for; the caller orders `fold_on` behind this launch's stream."""
     D = x.shape[-1]
     R = x.numel() // D
     dx = torch.empty_like(x)
@@ -276,9 +278,14 @@ def add_ln_bwd(dout, x, residual, gamma, mean, rstd, dgamma, dbeta, p_drop=0.0, 
     if LN_TWO_STAGE and dgamma is not None and R >= 256:
         prow = min(1024, (R + 3) // 4)
         part = torch.empty((prow, 2, D), device=x.device, dtype=torch.float32)     # scratch of the two-stage dgamma/dbeta fold
+    defer = fold_on is not None and part is not None and fold_on != _stream()
     call_struct("vacnic_add_ln_bwd", stream=_stream(), dout=_p(dout), x=_p(x), residual=_p(residual), gamma=_p(gamma),
                 mean=_p(mean), rstd=_p(rstd), dresidual=_p(dres), dx=_p(dx), dgamma=_p(dgamma), dbeta=_p(dbeta),
-                R=R, D=D, p_drop=p_drop, seed=seed, seed_dev=_p(seed_dev), partials=_p(part), partial_rows=prow)
+                R=R, D=D, p_drop=p_drop, seed=seed, seed_dev=_p(seed_dev), partials=_p(part), partial_rows=prow, defer_fold=int(defer))
+    if defer:
+        fence(_stream(), fold_on)
+        with launch_on(fold_on, fence=False):
+            call("vacnic_ln_partial_fold", _p(part), _p(dgamma), _p(dbeta), prow, D, _stream())
     return dx, (dres if dres is not None else dx)
 
 

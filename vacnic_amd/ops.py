@@ -20,6 +20,7 @@ from . import streams
 
 BF16 = torch.bfloat16
 _NO_XSUM = __import__("os").environ.get("VACNIC_NO_XSUM") == "1"
+_LN_FOLD_ON_SIDE = __import__("os").environ.get("VACNIC_LN_FOLD_MAIN") != "1"      # A/B: 1 = the fold stays in the backward chain
 _FUSE_ACT_DROPOUT = __import__("os").environ.get("VACNIC_FUSE_ACT_DROPOUT", "1") != "0"      # A/B: 0 = separate in-place dropout passes
 
 
@@ -639,9 +640,11 @@ class AddLnFn(Function):
     def backward(ctx, dout):
         x, res, mean, rstd = ctx.saved_tensors
         gamma, beta = ctx.gb
+        # the fold of the LayerNorm parameter gradients (needed by AdamW / the reducer only) rides on the weight-gradient stream
+        side = streams.wgrad_raw() if (streams.explicit() and streams.wgrad_stream() is not None and _LN_FOLD_ON_SIDE) else None
         dx, dres = K.add_ln_bwd(_c(dout), x, res, gamma, mean, rstd, gamma.grad, beta.grad, p_drop=ctx.p, seed=ctx.seed,
                                 seed_dev=Rng.device_counter() if ctx.p > 0 else None,
-                                need_dres=ctx.has_res and ctx.needs_input_grad[1])
+                                need_dres=ctx.has_res and ctx.needs_input_grad[1], fold_on=side)
         ddp.done(gamma.grad, beta.grad)
         return (dx if ctx.needs_input_grad[0] else None), (dres if ctx.has_res and ctx.needs_input_grad[1] else None), None, None, None, None, None
 
