@@ -483,12 +483,18 @@ def main():
             towers = None
     # the process group comes up only now: the tower graphs above are captured with no communicator (and no watchdog thread
     # issuing HIP calls) alive in the process
+    # VACNIC_BENCH_FORCE_DDP=1 at --gpus 1: a ONE-rank RCCL communicator and the whole reducer path (bucket all-reduces on the comm
+    # stream from inside the plan replay, pipelined AdamW) — the N > 1 code running on real RCCL on the one GPU a gpurun box has
+    force_ddp = world == 1 and os.environ.get("VACNIC_BENCH_FORCE_DDP") == "1"
+    if force_ddp:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend, rank=0, world_size=1, **({"device_id": torch.device("cuda", local)} if backend == "nccl" else {}))
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
-    net = DistributedDataParallel(model, grad_transport=a.grad_transport) if world > 1 else model
+    net = DistributedDataParallel(model, grad_transport=a.grad_transport, force_reducer=force_ddp) if (world > 1 or force_ddp) else model
     use_graph = world == 1 and a.graph
     log(f"batches resident; warm-up ({'hipGraph capture' if use_graph else 'eager'})")
     graphed = None
@@ -630,12 +636,13 @@ def main():
                "host_launch_path_ms_per_step": round(host_idle_gpu * 1e3, 2) if host_idle_gpu is not None else None,
                "per_rank_ms_per_step": per_rank_ms,
                "world_size_reported": dist.get_world_size() if world > 1 else 1,
-               "dist_backend": (backend if world > 1 else None), "grad_transport": (a.grad_transport if world > 1 else None),
+               "dist_backend": (backend if (world > 1 or force_ddp) else None), "grad_transport": (a.grad_transport if (world > 1 or force_ddp) else None),
+               "forced_one_rank_reducer": bool(force_ddp),
                "step_tflops_per_gpu": round(value / world * gf / 1e3, 1) if gf else None,
                "step_mfma_frac": round(value / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4) if gf else None,
                "losses_last_step": {"total": losses[0], "txt": losses[1], "secla": losses[2], "colam": losses[3]},
                "roofline": roof}
-        if world == 1 and not a.no_extras:
+        if world == 1 and not a.no_extras and not force_ddp:
             try:
                 res["target_gemm"] = target_gemm_leg()
                 res["extra"] = {"config5_generation": decode_leg(model, cfg)}
@@ -654,7 +661,7 @@ def main():
             except Exception as e:      # the baseline must never sink the GPU measurement
                 res["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
         print(json.dumps(res))
-    if world > 1:
+    if world > 1 or force_ddp:
         dist.destroy_process_group()
 
 

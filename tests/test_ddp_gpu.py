@@ -277,3 +277,69 @@ def test_planned_step_at_world_2_trains_like_the_eager_ddp_step():
         for transport in ("fp32", "bf16"):
             v = r[2][transport]
             assert v["finite"] and v["loss_rel"] <= 2e-3 and v["weight_rel"] <= 1e-4, (r[0], transport, v)
+
+
+def _worker_rccl(q, port):
+    """ONE rank, the REAL communication library: a one-rank RCCL communicator on the GPU and the whole reducer path forced on
+    (DistributedDataParallel(force_reducer=True)) — tracker, bucket all-reduces launched on the comm stream while backward runs,
+    waits, pipelined AdamW, eager and as host actions of a launch plan, fp32 and bf16 transport.  A sum over one rank is the
+    identity, so the run must train exactly like the plain single-GPU step."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    try:
+        torch.cuda.set_device(0)
+        from vacnic_amd import ddp, ops, streams, synthetic
+        from vacnic_amd.training import FusedAdamW, PlannedTrainStep, TrainArgs, build_models, train_step
+        streams.enable(True)
+        cfg, vcfg = _cfgs()
+        args = TrainArgs(num_training_steps=20, warmup_rate=0.1, lr_bart=1e-4)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        batches = [{k: v.cuda() for k, v in synthetic.make_batch(cfg, B, S=S, T=T, F=F, seed=70 + i, image_size=32).items()} for i in range(3)]
+        order = batches[1:] + batches[:1]
+        runs = {}
+        for mode in ("plain", "rccl_eager", "rccl_plan", "rccl_plan_bf16"):
+            ops.Rng.manual_seed(3); ops.Rng.device_counter().zero_()
+            model, guide, _ = build_models(cfg, vcfg, init="synthetic", seed=3)
+            model.train()
+            net = model if mode == "plain" else ddp.DistributedDataParallel(model, bucket_bytes=8 << 20, force_reducer=True,
+                                                                           grad_transport="bf16" if mode.endswith("bf16") else "fp32")
+            if mode != "plain":
+                assert net.active and net.world == 1 and ddp.TRACKER is net.tracker and net.comm_stream is not None
+            opt = FusedAdamW(model.arena, lr=args.lr_bart, weight_decay=args.weight_decay, num_warmup_steps=2, num_training_steps=20)
+            if "plan" in mode:
+                step = PlannedTrainStep(net, guide, opt, args, batches[0], warmup=2)
+                assert sum(1 for m in step.marks if callable(m[1])) == 2 * len(net.tracker.buckets) + 1
+                losses = [step(b).tolist() for b in order]
+                step.close()
+            else:
+                for _ in range(3):
+                    train_step(net, guide, opt, batches[0], args)
+                losses = [train_step(net, guide, opt, b, args).tolist() for b in order]
+            torch.cuda.synchronize()
+            runs[mode] = (losses, model.arena.flat32.clone())
+            ddp.TRACKER = None
+            del net, opt, model, guide
+        res = {}
+        for mode in ("rccl_eager", "rccl_plan", "rccl_plan_bf16"):
+            dl = max(abs(a - b) / max(abs(b), 1e-6) for la, lb in zip(runs[mode][0], runs["plain"][0]) for a, b in zip(la, lb))
+            dw = ((runs[mode][1] - runs["plain"][1]).double().norm() / runs["plain"][1].double().norm()).item()
+            res[mode] = (dl, dw)
+        q.put(("ok", res))
+    except Exception:
+        import traceback
+        q.put(("FAIL: " + traceback.format_exc(), None))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_one_rank_rccl_reducer_trains_like_the_plain_step():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_rccl, args=(q, 30100 + (os.getpid() % 2000)))
+    p.start()
+    status, res = q.get(timeout=600)
+    p.join(timeout=120)
+    assert status == "ok", status
+    for mode in ("rccl_eager", "rccl_plan"):                      # the identity all-reduce: the same training run (LayerNorm atomics aside)
+        assert res[mode][0] <= 2e-3 and res[mode][1] <= 1e-4, (mode, res[mode])
+    assert res["rccl_plan_bf16"][0] <= 5e-3 and res["rccl_plan_bf16"][1] <= 5e-4, res["rccl_plan_bf16"]    # gradients rounded to bf16 on the wire

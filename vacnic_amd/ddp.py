@@ -96,12 +96,16 @@ class DistributedDataParallel(torch.nn.Module):
     (or use `vacnic_amd.training.train_step`, which does).  With world_size 1 it is a no-op shell."""
 
     def __init__(self, module, device_ids=None, output_device=None, process_group=None, bucket_bytes=256 << 20,
-                 overlap=True, grad_transport="fp32"):
+                 overlap=True, grad_transport="fp32", force_reducer=False):
+        """force_reducer: run the whole reducer (tracker, bucket launches on the comm stream, waits, pipelined AdamW) even on a
+        ONE-rank process group — every collective then executes on the real communicator (RCCL on one GPU) although it has nobody
+        to talk to.  A rehearsal aid for boxes with a single GPU (bench.py VACNIC_BENCH_FORCE_DDP=1, tests/test_ddp_gpu.py)."""
         super().__init__()
         global TRACKER
         self.module = module
         self.pg = process_group
         self.world = dist.get_world_size(self.pg) if dist.is_available() and dist.is_initialized() else 1
+        self.active = self.world > 1 or (bool(force_reducer) and dist.is_available() and dist.is_initialized())
         self.arena = module.arena
         if self.arena is None or self.arena.grad is None:
             raise RuntimeError("wrap a finalized trainable model (module.finalize(device) first)")
@@ -118,9 +122,9 @@ class DistributedDataParallel(torch.nn.Module):
             raise ValueError("grad_transport must be 'fp32' or 'bf16'")
         self.transport = grad_transport
         self.stage16 = None
-        if self.world > 1 and grad_transport == "bf16":
+        if self.active and grad_transport == "bf16":
             self.stage16 = torch.empty(self.arena.n, device=self.arena.grad.device, dtype=torch.bfloat16)
-        if self.world > 1:
+        if self.active:
             # (i) ctor broadcast of all params from rank 0 (TRAIN:87); buffers on this path are constants
             dist.broadcast(self.arena.flat32, src=0, group=self.pg)
             self.arena.refresh_shadow()
@@ -201,7 +205,7 @@ class DistributedDataParallel(torch.nn.Module):
     def reduce_gradients(self):
         """Finish the step's gradient all-reduce: launch whatever backward did not already launch, then make the
         compute stream wait for every bucket.  Gradients hold the SUM over ranks afterwards (AdamW divides)."""
-        if self.world == 1:
+        if not self.active:
             return
         for start, _ in self.tracker.buckets:
             self._launch_bucket(start)
@@ -215,7 +219,7 @@ class DistributedDataParallel(torch.nn.Module):
         embedding tables: ~1 GB of fp32 gradients that cannot overlap with backward) are still on the links while the
         optimizer's ~5.5 ms of HBM traffic for the other ~2.5 GB runs, instead of after them.  With gradient clipping the global
         norm needs every bucket first: plain reduce, then one step."""
-        if self.world == 1 or clip_norm is not None:
+        if not self.active or clip_norm is not None:
             self.reduce_gradients()
             optimizer.step(clip_norm=clip_norm)
             return
