@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--no-plan", action="store_true", help="issue every step from Python (eager) instead of replaying the recorded launch "
                     "plan (vacnic_plan_replay: the same multi-stream schedule re-issued from C++, a handful of C-ABI calls per step). "
                     "Same-box A/B: 68.4 vs 68.6 ms per step; launch path 7 vs 24 ms of host time per step")
+    ap.add_argument("--no-roofline-step", action="store_true", help="A/B aid: every timed step runs in the launch mode under test (the last one "
+                    "is normally an eager single-stream step with HIP events around every GEMM, the roofline measurement); the roofline object is then null")
     ap.add_argument("--mock-step", action="store_true", help=argparse.SUPPRESS)    # tests/test_bench_launch.py: launcher plumbing without a GPU
     return ap.parse_args()
 
@@ -442,6 +444,12 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch one process per GPU")
+    # stdout carries exactly ONE line, rank 0's JSON: the communication libraries announce themselves on fd 1 (RCCL prints a
+    # version banner when its first communicator comes up, gloo its peers), so fd 1 is pointed at stderr for the whole run and the
+    # JSON line is written to a private duplicate of the original stdout
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     # VACNIC_DIST_BACKEND=gloo VACNIC_SINGLE_DEVICE=1: rehearse the N>1 code path (tracker, bucket launches, side streams,
     # joins) with several ranks sharing ONE GPU — RCCL itself needs one GPU per rank, which only the driver's node has
     single_dev = os.environ.get("VACNIC_SINGLE_DEVICE") == "1"
@@ -540,7 +548,7 @@ def main():
     out4 = None
     for i in range(a.steps):
         bt = batches[(a.warmup + i) % nb]
-        if i == a.steps - 1:
+        if i == a.steps - 1 and not a.no_roofline_step:
             # last timed step: single-stream eager launches with HIP events around every GEMM launch, so each bracket times
             # ONE kernel alone on the GPU (with side streams the brackets would overlap other kernels) — this is the
             # roofline measurement of the dominant kernel, taken inside the timed region (it costs ~12 ms of throughput once)
@@ -554,7 +562,8 @@ def main():
             out4 = planned(bt, ready)
         else:
             out4 = train_step(net, guide, opt, bt, args, ready, towers)
-    timer.remove()
+    if not a.no_roofline_step:
+        timer.remove()
     host_dt = time.perf_counter() - t0           # host-side enqueue time of the K steps (GPU may still be running)
     calls_per_step = (_vlib.CALLS - calls0) / a.steps
     host_cpu = (time.thread_time() - cpu0) / a.steps     # CPU time of the launching thread (enqueue wall time also contains back-pressure waits)
@@ -660,7 +669,8 @@ def main():
                 log("cpu baseline done")
             except Exception as e:      # the baseline must never sink the GPU measurement
                 res["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
-        print(json.dumps(res))
+        json_out.write(json.dumps(res) + "\n")
+        json_out.flush()
     if world > 1 or force_ddp:
         dist.destroy_process_group()
 

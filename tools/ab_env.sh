@@ -7,7 +7,7 @@ out=gpurun_out/${tag}.txt
 for round in 1 2; do
   for e in "$@"; do
     [ "$e" = "-" ] && e=""
-    ms=$(env $e python3 bench.py --no-cpu-baseline --no-extras --steps 24 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])")
+    ms=$(env $e python3 bench.py --no-cpu-baseline --no-extras --steps 24 $BENCH_FLAGS 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])")
     echo "round $round  [${e:-default}]  ms/step, samples/s: $ms" | tee -a $out
   done
 done

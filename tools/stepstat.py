@@ -12,7 +12,13 @@ for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
         n = re.sub(r"\(anonymous namespace\)::", "", n)
         n = re.sub(r"^void ", "", n)[:70]
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), n))
-adam = sorted(e for s, e, n in rows if n.startswith("adamw_kernel"))
+adam_all = sorted(e for s, e, n in rows if n.startswith("adamw_kernel"))
+adam = []                                       # one time stamp per step: the END of its last AdamW launch (the pipelined optimizer of the
+for e in adam_all:                              # data-parallel reducer launches AdamW once per gradient bucket, a few ms apart)
+    if adam and e - adam[-1] < 20e6:
+        adam[-1] = e
+    else:
+        adam.append(e)
 if len(adam) < K + 1:
     sys.exit(f"stepstat: {len(adam)} AdamW launches in the trace, need {K + 1} to delimit {K} timed steps")
 steps = K - 1                                   # the last timed step of bench.py is the eager instrumented one
