@@ -453,7 +453,11 @@ def main():
     # VACNIC_DIST_BACKEND=gloo VACNIC_SINGLE_DEVICE=1: rehearse the N>1 code path (tracker, bucket launches, side streams,
     # joins) with several ranks sharing ONE GPU — RCCL itself needs one GPU per rank, which only the driver's node has
     single_dev = os.environ.get("VACNIC_SINGLE_DEVICE") == "1"
-    backend = os.environ.get("VACNIC_DIST_BACKEND", "nccl")
+    # N > 1: the gradient all-reduce is RCCL through the C-ABI (vacnic_amd/csrc/comm.hip, the reducer's "native" path);
+    # torch.distributed is the control plane only (rendezvous, the 128-byte communicator id, barriers, the max-over-ranks of the
+    # timing) and runs over gloo on CPU tensors, so that no second GPU communicator and no extra GPU stream exist in the process.
+    # VACNIC_DDP_COMM=wgrad|own + VACNIC_DIST_BACKEND=nccl: the collectives through torch.distributed (ProcessGroupNCCL) instead.
+    backend = os.environ.get("VACNIC_DIST_BACKEND", "gloo" if os.environ.get("VACNIC_DDP_COMM", "native") == "native" else "nccl")
     torch.cuda.set_device(0 if single_dev else local)
     if os.environ.get("VACNIC_MAIN_PRIORITY") is not None:      # A/B aid: the compute stream as a HIP stream of that priority
         torch.cuda.set_stream(torch.cuda.Stream(priority=int(os.environ["VACNIC_MAIN_PRIORITY"])))
@@ -497,12 +501,35 @@ def main():
     if force_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend, rank=0, world_size=1, **({"device_id": torch.device("cuda", local)} if backend == "nccl" else {}))
+    if world == 1 and os.environ.get("VACNIC_BENCH_INIT_PG_ONLY") == "4":      # A/B aid: two more HIP streams that ran one tiny kernel each
+        _extra = [torch.cuda.Stream() for _ in range(2)]
+        for s_ in _extra:
+            with torch.cuda.stream(s_):
+                torch.zeros(16, device="cuda").add_(1.0)
+        torch.cuda.synchronize()
+    if world == 1 and os.environ.get("VACNIC_BENCH_INIT_PG_ONLY") == "3":      # A/B aid: an idle extra host thread, nothing else
+        import threading
+        threading.Thread(target=lambda: time.sleep(3600), daemon=True).start()
+    if world == 1 and os.environ.get("VACNIC_BENCH_INIT_PG_ONLY") == "2":      # A/B aid: the process group without any collective
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29535")
+        dist.init_process_group(backend, rank=0, world_size=1)
+    if world == 1 and os.environ.get("VACNIC_BENCH_INIT_PG_ONLY") == "1":
+        # A/B aid: a one-rank process group (communicator + one broadcast) beside the plain single-GPU step, no reducer
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29534")
+        dist.init_process_group(backend, rank=0, world_size=1, **({"device_id": torch.device("cuda", local)} if backend == "nccl" else {}))
+        dist.broadcast(model.arena.flat32, src=0)
+        torch.cuda.synchronize()
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
-    net = DistributedDataParallel(model, grad_transport=a.grad_transport, force_reducer=force_ddp) if (world > 1 or force_ddp) else model
+    ddp_kw = {}
+    if os.environ.get("VACNIC_DDP_BUCKET_MB"):                  # A/B aids for the reducer
+        ddp_kw["bucket_bytes"] = int(os.environ["VACNIC_DDP_BUCKET_MB"]) << 20
+    if os.environ.get("VACNIC_DDP_OVERLAP") == "0":
+        ddp_kw["overlap"] = False
+    net = DistributedDataParallel(model, grad_transport=a.grad_transport, force_reducer=force_ddp, **ddp_kw) if (world > 1 or force_ddp) else model
     use_graph = world == 1 and a.graph
     log(f"batches resident; warm-up ({'hipGraph capture' if use_graph else 'eager'})")
     graphed = None
@@ -574,7 +601,7 @@ def main():
     dt = time.perf_counter() - t0
     per_rank_ms = [round(dt / a.steps * 1e3, 2)]
     if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         every = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(every, t)
         per_rank_ms = [round(v.item() / a.steps * 1e3, 2) for v in every]
@@ -646,6 +673,8 @@ def main():
                "per_rank_ms_per_step": per_rank_ms,
                "world_size_reported": dist.get_world_size() if world > 1 else 1,
                "dist_backend": (backend if (world > 1 or force_ddp) else None), "grad_transport": (a.grad_transport if (world > 1 or force_ddp) else None),
+               "gradient_allreduce": (("RCCL through the C-ABI (vacnic_allreduce_bucket), recorded in the launch plan" if getattr(net, "native", None) is not None
+                                       else "torch.distributed collectives") if (world > 1 or force_ddp) else None),
                "forced_one_rank_reducer": bool(force_ddp),
                "step_tflops_per_gpu": round(value / world * gf / 1e3, 1) if gf else None,
                "step_mfma_frac": round(value / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4) if gf else None,

@@ -497,6 +497,26 @@ int vacnic_plan_replay(int64_t plan, int64_t first, int64_t last);
 int vacnic_plan_destroy(int64_t plan);
 int vacnic_stream_fence(void* src_stream, void* dst_stream);
 
+/* ---- data-parallel communication: RCCL behind the C-ABI ------------------------------------------------------------------------
+ * The reference's DDP wrapper (torch.nn.parallel.DistributedDataParallel over NCCL, TRAIN:87) all-reduces gradient buckets from
+ * C++ hooks; here a bucket's SUM all-reduce is a stream-ordered launch on a stream the caller names, recordable into a launch
+ * plan like any kernel.  librccl is resolved with dlopen (vacnic_comm_load; path = NULL searches the usual names), so the
+ * library loads on a box without RCCL and these entry points then return VACNIC_UNSUPPORTED.
+ *   vacnic_comm_unique_id   rank 0: 128 opaque bytes to hand to every rank out of band (ncclGetUniqueId)
+ *   vacnic_comm_init        every rank, with its GPU current: communicator handle >= 0, or -1 (ncclCommInitRank)
+ *   vacnic_allreduce_bucket in-place SUM over the communicator, dtype 0 = f32, 1 = bf16 (ncclAllReduce)
+ *   vacnic_comm_broadcast   in-place broadcast from `root` (the parameter broadcast at construction, TRAIN:87)
+ *   vacnic_event_record / vacnic_event_wait   named events (slots 0 .. 511): the consumer stream waits for ONE point of the
+ *                           producer stream (a bucket's all-reduce), whatever that stream is given afterwards */
+int vacnic_comm_load(const char* librccl_path);
+int vacnic_comm_unique_id(void* out128);
+int64_t vacnic_comm_init(const void* id128, int rank, int world);
+int vacnic_allreduce_bucket(int64_t comm, void* buf, int64_t count, int dtype, void* stream);
+int vacnic_comm_broadcast(int64_t comm, void* buf, int64_t count, int dtype, int root, void* stream);
+int vacnic_comm_destroy(int64_t comm);
+int vacnic_event_record(int slot, void* stream);
+int vacnic_event_wait(int slot, void* stream);
+
 /* ---- hardware probes (tests only): verify MFMA / ds_read_tr lane maps assumed by the kernels -- */
 int vacnic_probe_layouts(float* out, const float* src128, int64_t n_out, void* stream);
 

@@ -292,22 +292,28 @@ def _worker_rccl(q, port):
         streams.enable(True)
         cfg, vcfg = _cfgs()
         args = TrainArgs(num_training_steps=20, warmup_rate=0.1, lr_bart=1e-4)
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        dist.init_process_group("gloo", rank=0, world_size=1)          # control plane only: the data plane is RCCL through the C-ABI
         batches = [{k: v.cuda() for k, v in synthetic.make_batch(cfg, B, S=S, T=T, F=F, seed=70 + i, image_size=32).items()} for i in range(3)]
         order = batches[1:] + batches[:1]
         runs = {}
-        for mode in ("plain", "rccl_eager", "rccl_plan", "rccl_plan_bf16"):
+        for mode in ("plain", "rccl_eager", "rccl_plan", "rccl_plan_bf16", "torch_plan"):
             ops.Rng.manual_seed(3); ops.Rng.device_counter().zero_()
             model, guide, _ = build_models(cfg, vcfg, init="synthetic", seed=3)
             model.train()
+            if mode == "torch_plan":                       # the torch.distributed data plane (collectives as host actions of the plan)
+                ddp._COMM_MODE = "wgrad"
             net = model if mode == "plain" else ddp.DistributedDataParallel(model, bucket_bytes=8 << 20, force_reducer=True,
                                                                            grad_transport="bf16" if mode.endswith("bf16") else "fp32")
-            if mode != "plain":
-                assert net.active and net.world == 1 and ddp.TRACKER is net.tracker and net.comm_stream is not None
+            ddp._COMM_MODE = "native"
+            if mode == "torch_plan":
+                assert net.native is None and net.comm_on_wgrad
+            elif mode != "plain":
+                assert net.active and net.world == 1 and ddp.TRACKER is net.tracker and net.native is not None, "RCCL through the C-ABI (vacnic_allreduce_bucket) must be the data plane"
             opt = FusedAdamW(model.arena, lr=args.lr_bart, weight_decay=args.weight_decay, num_warmup_steps=2, num_training_steps=20)
             if "plan" in mode:
                 step = PlannedTrainStep(net, guide, opt, args, batches[0], warmup=2)
-                assert sum(1 for m in step.marks if callable(m[1])) == 2 * len(net.tracker.buckets) + 1
+                hosts = sum(1 for m in step.marks if callable(m[1]))
+                assert hosts == (2 * len(net.tracker.buckets) + 1 if mode == "torch_plan" else 0), (mode, hosts)   # native: plan commands, no host actions
                 losses = [step(b).tolist() for b in order]
                 step.close()
             else:
@@ -319,7 +325,7 @@ def _worker_rccl(q, port):
             ddp.TRACKER = None
             del net, opt, model, guide
         res = {}
-        for mode in ("rccl_eager", "rccl_plan", "rccl_plan_bf16"):
+        for mode in ("rccl_eager", "rccl_plan", "rccl_plan_bf16", "torch_plan"):
             dl = max(abs(a - b) / max(abs(b), 1e-6) for la, lb in zip(runs[mode][0], runs["plain"][0]) for a, b in zip(la, lb))
             dw = ((runs[mode][1] - runs["plain"][1]).double().norm() / runs["plain"][1].double().norm()).item()
             res[mode] = (dl, dw)
@@ -340,6 +346,6 @@ def test_one_rank_rccl_reducer_trains_like_the_plain_step():
     status, res = q.get(timeout=600)
     p.join(timeout=120)
     assert status == "ok", status
-    for mode in ("rccl_eager", "rccl_plan"):                      # the identity all-reduce: the same training run (LayerNorm atomics aside)
+    for mode in ("rccl_eager", "rccl_plan", "torch_plan"):        # the identity all-reduce: the same training run (LayerNorm atomics aside)
         assert res[mode][0] <= 2e-3 and res[mode][1] <= 1e-4, (mode, res[mode])
     assert res["rccl_plan_bf16"][0] <= 5e-3 and res["rccl_plan_bf16"][1] <= 5e-4, res["rccl_plan_bf16"]    # gradients rounded to bf16 on the wire

@@ -9,7 +9,13 @@ for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Stream_Id", r.get("Queue_Id", "?"))))
 print("columns:", hdr)
 rows.sort()
-ad = [i for i, r in enumerate(rows) if "adamw_kernel" in r[2]]
+ad_all = [i for i, r in enumerate(rows) if "adamw_kernel" in r[2]]
+ad = []                                    # last AdamW launch of every step (the reducer's pipelined optimizer launches one per bucket)
+for i in ad_all:
+    if ad and rows[i][1] - rows[ad[-1]][1] < 20e6:
+        ad[-1] = i
+    else:
+        ad.append(i)
 lo, hi = ad[-4], ad[-3]
 t0, t1 = rows[lo][1], rows[hi][1]
 sel = [r for r in rows if r[1] > t0 and r[0] < t1]

@@ -107,7 +107,11 @@ def run(args, batches=None):
     local = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0"))
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        # torch.distributed is the control plane (rendezvous, the RCCL communicator id); the gradient all-reduce itself is RCCL
+        # through the C-ABI on the reducer's native path (vacnic_amd/ddp.py).  VACNIC_DIST_BACKEND=nccl + VACNIC_DDP_COMM=wgrad: the
+        # reference's arrangement (TRAIN:87, collectives through ProcessGroupNCCL)
+        be = os.environ.get("VACNIC_DIST_BACKEND", "gloo" if os.environ.get("VACNIC_DDP_COMM", "native") == "native" else "nccl")
+        dist.init_process_group(backend=be, **({"device_id": torch.device("cuda", local)} if be == "nccl" else {}))
     ops.Rng.manual_seed(int(args.seed) + rank)
     streams.enable(True)                     # guide forward + weight gradients on side streams
     vkw = CLIP[args.clip_type]

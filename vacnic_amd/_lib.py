@@ -180,11 +180,14 @@ _PLAIN_FNS = {
     "vacnic_plan_end": [i64], "vacnic_plan_replay": [i64, i64, i64], "vacnic_plan_destroy": [i64], "vacnic_stream_fence": [vp, vp],
     "vacnic_plan_pause": [i32],
     "vacnic_ln_partial_fold": [vp, vp, vp, i64, i64, vp],
+    "vacnic_comm_load": [C.c_char_p], "vacnic_comm_unique_id": [vp], "vacnic_allreduce_bucket": [i64, vp, i64, i32, vp],
+    "vacnic_comm_broadcast": [i64, vp, i64, i32, i32, vp], "vacnic_comm_destroy": [i64],
+    "vacnic_event_record": [i32, vp], "vacnic_event_wait": [i32, vp],
     "vacnic_beam_step": [C.POINTER(BeamState), vp, vp, i32, i32, vp],
 }
 EXPORTED = sorted(list(_STRUCT_FNS) + list(_PLAIN_FNS) + ["vacnic_last_error_string", "vacnic_version", "vacnic_decoder_step_sync_bytes", "vacnic_decoder_step_slots_bytes",
                                                             "vacnic_plan_begin", "vacnic_plan_size", "vacnic_plan_mark",
-                                                            "vacnic_gemm_workspace_bytes", "vacnic_gemm_counters"])
+                                                            "vacnic_gemm_workspace_bytes", "vacnic_gemm_counters", "vacnic_comm_init"])
 
 for _name, _st in _STRUCT_FNS.items():
     _fn = getattr(lib, _name)          # AttributeError here = stale .so: fail loudly
@@ -212,6 +215,8 @@ lib.vacnic_gemm_workspace_bytes.restype = C.c_int64
 lib.vacnic_gemm_workspace_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int64]
 lib.vacnic_gemm_counters.restype = C.c_int64
 lib.vacnic_gemm_counters.argtypes = [C.c_int64, C.c_int64]
+lib.vacnic_comm_init.restype = C.c_int64
+lib.vacnic_comm_init.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
 
 _VALUE_ERRORS = (1, 2, 3)   # bad shape / dtype / alignment -> ValueError like the reference's shape checks
 

@@ -76,6 +76,46 @@ def _p(t):
     return t.data_ptr()
 
 
+# ------------------------------------------------------------------------------------- communication
+def comm_load():
+    """resolve librccl for the comm entry points (the copy torch ships and has already loaded, else the system one)."""
+    import os
+    p = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    call("vacnic_comm_load", p.encode() if os.path.exists(p) else None)
+
+
+def comm_unique_id():
+    buf = _lib.C.create_string_buffer(128)
+    call("vacnic_comm_unique_id", buf)
+    return buf.raw
+
+
+def comm_init(id128, rank, world):
+    h = int(_lib.lib.vacnic_comm_init(_lib.C.c_char_p(id128), rank, world))
+    if h < 0:
+        _lib.check(4)
+    return h
+
+
+def allreduce_bucket(comm, t):
+    """in-place SUM all-reduce of a contiguous fp32 / bf16 tensor over the RCCL communicator, on the launch stream."""
+    assert t.is_contiguous() and t.dtype in (torch.float32, BF16)
+    call("vacnic_allreduce_bucket", comm, _p(t), t.numel(), 0 if t.dtype == torch.float32 else 1, _stream())
+
+
+def comm_broadcast(comm, t, root=0):
+    assert t.is_contiguous() and t.dtype in (torch.float32, BF16)
+    call("vacnic_comm_broadcast", comm, _p(t), t.numel(), 0 if t.dtype == torch.float32 else 1, root, _stream())
+
+
+def event_record(slot, stream=None):
+    call("vacnic_event_record", slot, stream if stream is not None else _stream())
+
+
+def event_wait(slot, stream=None):
+    call("vacnic_event_wait", slot, stream if stream is not None else _stream())
+
+
 def recording():
     """a launch plan is being recorded by this process (vacnic_plan_begin .. vacnic_plan_end)."""
     return int(_lib.lib.vacnic_plan_mark()) >= 0

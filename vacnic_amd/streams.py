@@ -112,14 +112,24 @@ def vit_stream():
     return _state["vit"] if _state["enabled"] else None
 
 
-def join_all():
-    """make the current stream wait for everything issued on the side streams (before AdamW / the all-reduce tail)."""
+def release_keep():
+    """drop the references held for the side streams (the caller has ordered the compute stream behind all of them)."""
+    _state["keep"].clear()
+
+
+def join_all(skip_wgrad=False):
+    """make the current stream wait for everything issued on the side streams (before AdamW / the all-reduce tail).
+    skip_wgrad: the weight-gradient stream is joined piecewise by the data-parallel reducer (one named event per gradient bucket,
+    the last of them behind everything that stream was given); the keep-list then stays until release_keep()."""
     if _state["enabled"] and _state["explicit"]:
         cur = _K._stream()
         for name in ("wgrad", "aux", "vit", "branch"):
+            if name == "wgrad" and skip_wgrad:
+                continue
             if name != "vit" or _state["vit"] is not _state["aux"]:
                 _K.fence(_state[name].cuda_stream, cur)
-        _state["keep"].clear()
+        if not skip_wgrad:
+            _state["keep"].clear()
         return
     if _state["enabled"]:
         cur = torch.cuda.current_stream()

@@ -275,12 +275,17 @@ def train_step(model, guide, optimizer, batch, args: TrainArgs, ready=None, towe
         # block per step — the one ATen kernel left inside the step (tools/aten_in_step.py), invisible to a launch plan
         total.backward(ops.const_one(total.device))
     ops.flush_wgrads()                       # normally empty (the engine's end-of-backward callback already ran)
-    streams.join_all()                       # weight-gradient side stream -> compute stream
+    clip = None if args.no_clip_norm else args.clip_norm                         # TRAIN:365-366
+    # native reducer: the bucket all-reduces sit ON the weight-gradient stream, and every bucket's AdamW range waits for that
+    # bucket's own event — joining the whole stream here would hold AdamW back until the LAST collective has finished
+    pipelined = isinstance(model, DistributedDataParallel) and model.native is not None and model.active and clip is None
+    streams.join_all(skip_wgrad=pipelined)   # side streams -> compute stream
     if _PLAN is not None and _PLAN.towers is not None:
         _PLAN.mark("backward_done")          # (the host can start the next step's guide graph behind this point)
-    clip = None if args.no_clip_norm else args.clip_norm                         # TRAIN:365-366
     if isinstance(model, DistributedDataParallel):
         model.reduce_and_step(optimizer, clip)       # all-reduce tail overlapped with the optimizer of the finished buckets
+        if pipelined:
+            streams.release_keep()           # the last bucket's event is behind everything the weight-gradient stream was given
     else:
         optimizer.step(clip_norm=clip)
     optimizer.zero_grad()
