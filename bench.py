@@ -434,6 +434,7 @@ def self_launch(a):
 
 
 def main():
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "5")       # before the first HIP call of the process: see vacnic_amd/__init__.py
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(a))
