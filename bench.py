@@ -434,7 +434,8 @@ def self_launch(a):
 
 
 def main():
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "5")       # before the first HIP call of the process: see vacnic_amd/__init__.py
+    # before the first HIP call of the process: see vacnic_amd/__init__.py (several ranks rehearsing on ONE card share its queues)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "2" if os.environ.get("VACNIC_SINGLE_DEVICE") == "1" else "5")
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(a))

@@ -53,7 +53,7 @@ def _fwd_bwd(model, guide, batch, args):
 
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+                      HSA_ENABLE_IPC_MODE_LEGACY="0", GPU_MAX_HW_QUEUES="2")      # two processes on ONE card: 2 x 2 hardware queues (vacnic_amd/__init__.py)
     try:
         torch.cuda.set_device(0)
         from vacnic_amd import ddp, streams
@@ -201,7 +201,7 @@ def _worker_plan(rank, world, port, q):
     """2 ranks on one GPU: the launch plan at world > 1 (the reducer's collectives as host actions at the plan's marks)
     must train like the eager DDP step — same losses over three batches, same final weights."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+                      HSA_ENABLE_IPC_MODE_LEGACY="0", GPU_MAX_HW_QUEUES="2")      # two processes on ONE card: 2 x 2 hardware queues (vacnic_amd/__init__.py)
     try:
         torch.cuda.set_device(0)
         from vacnic_amd import _lib, ddp, ops, streams, synthetic
