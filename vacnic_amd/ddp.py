@@ -1,18 +1,23 @@
 """Data-parallel gradient reduction over RCCL/xGMI — replaces torch.nn.parallel.DistributedDataParallel
 (TRAIN:87, TRAINV:84, DDPINF:1089) for the arena-based model.
 
-One process per GPU (torch.distributed, backend "nccl" == RCCL on ROCm).  The path is pure data
-parallel: the only collectives are a parameter broadcast at construction and one
-SUM all-reduce of the fp32 gradient arena per step; averaging (1/world) is folded into the fused
-AdamW kernel (grad_scale).  Because gradients already live in ONE flat buffer there is no
-flatten/unflatten: buckets are contiguous slices.
+One process per GPU.  The path is pure data parallel: the only collectives are a parameter
+broadcast at construction and one SUM all-reduce of the gradient arena per step; averaging (1/world) is
+folded into the fused AdamW kernel (grad_scale).  Because gradients already live in ONE flat buffer there
+is no flatten/unflatten: buckets are contiguous slices.
+
+Data plane (default, `_COMM_MODE` "native"): RCCL through the C-ABI (csrc/comm.hip) on the weight-gradient
+stream; torch.distributed (gloo) is the control plane only — rendezvous, the 128-byte communicator id, the
+check that no two ranks share a GPU.  `VACNIC_DDP_COMM=wgrad|own` keeps the torch.distributed ("nccl" ==
+RCCL on ROCm) data plane of rounds 1-3 for comparison; on CPU (gloo tests) the torch path is the only one.
 
 Overlap with backward is exact, not heuristic: every op that will accumulate into a gradient slice
 registers a pending write in forward (GradTracker.expect) and retires it in backward right after it
 has enqueued its wgrad kernel (GradTracker.done).  When the pending count of a bucket reaches zero
-the reducer records an event on the compute stream, makes the comm stream wait for it, and launches
-that bucket's all-reduce there — large buckets (default 256 MiB: xGMI is point-to-point, 7 links per
-GPU, so few large collectives beat many 25 MiB ones) in the order backward completes them.
+the reducer fences the bucket's writer streams into the weight-gradient stream and launches that
+bucket's all-reduce there, followed by a named event the compute stream waits for right before the
+bucket's AdamW range — large buckets (default 256 MiB: xGMI is point-to-point, 7 links per GPU, so few
+large collectives beat many 25 MiB ones) in the order backward completes them.
 """
 import os
 

@@ -400,9 +400,10 @@ class PlannedTrainStep:
     What makes a step replayable: explicit scheduling (streams.explicit(): no stream synchronisation hidden inside torch), no
     host<->device sync and no ATen kernel inside the step, per-step scalars in device memory (LR, step and dropout counters:
     vacnic_lr_step), and every buffer at its recorded address — the recording runs inside a private allocator pool that is
-    kept, inputs are copied into static tensors before each replay.  world_size > 1: the DDP reducer's host-side work (bucket
-    all-reduces launched on the comm stream as backward completes them, the waits before each bucket's AdamW range) is registered
-    as host actions at marks of the plan (ddp.HOST_HOOK -> self.host) and repeated by the host at the same points of every replay."""
+    kept, inputs are copied into static tensors before each replay.  world_size > 1: on the reducer's native path the bucket
+    all-reduces, their events and the waits before each bucket's AdamW range are C-ABI calls and hence plan commands; on the
+    torch.distributed fallback they are host actions at marks of the plan (ddp.HOST_HOOK -> self.host), run unrecorded while the
+    recording is paused and repeated by the host at the same points of every replay."""
 
     def __init__(self, model, guide, optimizer, args: TrainArgs, example_batch, warmup=2, towers=None):
         """towers: a FrozenTowerGraphs — the two frozen networks then stay hipGraph replays on their own streams, launched by the
