@@ -369,6 +369,23 @@ int vacnic_beam_topk(const void* logits, const float* beam_scores, const int32_t
                      int32_t suppress_eos, int32_t forced_token, float* top_val, int32_t* top_idx, int64_t R, int64_t V,
                      int64_t ldl, int32_t K, int32_t logits_f32, void* stream);
 /*
+ * LM head + vacnic_beam_topk of the single-token decoder fused (MFULL:1997 `lm_head(outputs[0]) + final_logits_bias`, then the
+ * log_softmax -> processors -> + beam_scores -> topk of beam_search above): R <= 8 rows, d_model <= 1024.  The [R][V] logits never
+ * reach HBM unless `logits` (fp32 [R][ldl], optional: diagnostics) is given (matrix-core product, fp32 accumulation).
+ *   h bf16 [R][d] contiguous (final hidden rows); emb bf16 [V][ldw]; bias fp32 [V] or NULL; bans / beam_scores / eos / suppress_eos /
+ *   forced_token / top_val / top_idx as in vacnic_beam_topk with K = K2 (n_ban = row length of bans).
+ *   workspace: vacnic_lmhead_topk_workspace(R, V, K2) floats of caller-owned scratch (per-workgroup partial results).
+ *   forced_token >= 0: no logits are computed (h / emb / workspace may be NULL): the forced token scores beam_scores[r], the rest -inf.
+ */
+typedef struct {
+  const void* h; const void* emb; const float* bias; float* logits; float* workspace;
+  const float* beam_scores; const int32_t* bans; float* top_val; int32_t* top_idx;
+  int64_t R, V, d, ldw, ldl, workspace_floats;
+  int32_t n_ban, eos, suppress_eos, forced_token, K2;
+} vacnic_lmhead_topk_args;
+int64_t vacnic_lmhead_topk_workspace(int64_t R, int64_t V, int32_t K2);
+int vacnic_lmhead_topk(const vacnic_lmhead_topk_args* a, void* stream);
+/*
  * On-device beam-search bookkeeping: what transformers 4.18 BeamSearchScorer.process does on the host between
  * two decoder steps (TRAIN:513-520 -> GenerationMixin.beam_search), plus the NoRepeatNGram ban lists of the next position —
  * so the decode loop needs no device->host copy per token; the host reads this state once after the last position.

@@ -589,14 +589,14 @@ def test_config5_sensitive_fixture_all_beams_and_mutations(monkeypatch):
     orig_step = Gn.CachedDecoder.step
     floor = 2.0 * max(healthy_dev, 0.1)
     for what in ("position", "row"):
-        def step_corrupt(self, ids_t, t, what=what):
+        def step_corrupt(self, ids_t, t, what=what, **skw):
             if t == 20:
                 c = self.cache_at(t)
                 if what == "position":
                     c[:, :, 5, :].neg_()
                 else:
                     c[:, 0, :t, :].mul_(-4.0)                      # the best beam's row, every layer: garbage of the wrong sign and scale
-            return orig_step(self, ids_t, t)
+            return orig_step(self, ids_t, t, **skw)
         for kw in ({}, {"device_beams": False}):
             monkeypatch.setattr(Gn.CachedDecoder, "step", step_corrupt)
             got, nb = mutated(**kw)
@@ -679,6 +679,59 @@ def test_beam_topk_kernel_matches_torch():
     K.gather_rows(src, dst2, perm, 6, 32 * 4, row_stride_bytes=64 * 4, period=3)
     want = src[torch.tensor([2, 0, 0, 5, 3, 3])]
     assert torch.equal(dst2[:, :32], want[:, :32]) and bool((dst2[:, 32:] == -1.0).all())
+
+
+@pytest.mark.parametrize("V,d,R", [(50265, 1024, 5), (50265, 1024, 8), (1003, 256, 3), (260, 64, 1)])
+def test_lmhead_topk_fused_matches_gemm_then_beam_topk(V, d, R):
+    """vacnic_lmhead_topk (LM head + log_softmax + processors + top-2nb without [R, V] logits in HBM) against the two-launch chain it
+    replaces (skinny GEMM -> vacnic_beam_topk) and against torch in fp32: its optional logits output agrees with the skinny GEMM's, the
+    picks are exactly vacnic_beam_topk's on those logits (scores desc, token asc), scores to 1e-4."""
+    from vacnic_amd import kernels as K
+    g = torch.Generator().manual_seed(V + d + R)
+    Vp = (V + 7) // 8 * 8
+    emb = (torch.randn(Vp, d, generator=g) * 0.5).bfloat16().cuda()
+    h = torch.randn(R, d, generator=g).bfloat16().cuda()
+    bias = (torch.randn(V, generator=g) * 0.1).cuda()
+    bs = torch.randn(R, generator=g).cuda()
+    K2 = 10
+    ref = h.float() @ emb[:V].float().t() + bias
+    top = ref.topk(3, dim=1).indices.cpu()
+    bans = torch.full((R, 7), -1, dtype=torch.int32)
+    for r in range(R):
+        bans[r, 0] = int(top[r, 0]); bans[r, 3] = int(top[r, 2]); bans[r, 5] = (r * 97) % V       # the best and third-best tokens are banned
+    bans = bans.cuda()
+    for suppress in (False, True):
+        logits = torch.empty((R, Vp), device="cuda", dtype=torch.float32)
+        K.gemm(h, emb, R, V, d, bias=bias, out=logits, ldo=Vp, out_mode=1)
+        lg2 = torch.full((R, Vp), 7.0, device="cuda", dtype=torch.float32)
+        tv, ti = K.lmhead_topk(h, emb, V, K2, bias=bias, beam_scores=bs, bans=bans, eos=2, suppress_eos=suppress, logits=lg2)
+        # its logits (matrix cores, K split over 4 waves) against the skinny GEMM's (fp32 FMA chain): same bf16 products, another sum order
+        assert torch.allclose(lg2[:, :V], logits[:, :V], atol=2e-4 * math.sqrt(d), rtol=0) and bool((lg2[:, V:] == 7.0).all())
+        want_v, want_i = K.beam_topk(lg2, V, K2, beam_scores=bs, bans=bans, eos=2, suppress_eos=suppress)      # same logits -> same picks
+        assert torch.equal(ti, want_i), (ti, want_i)
+        assert torch.allclose(tv, want_v, atol=1e-4, rtol=0)
+        lp = torch.log_softmax(ref, -1)
+        for r in range(R):
+            for t in bans[r].tolist():
+                if t >= 0:
+                    lp[r, t] = -float("inf")
+        if suppress:
+            lp[:, 2] = -float("inf")
+        tw, iw = torch.topk(lp + bs[:, None], K2, dim=1)
+        assert torch.allclose(tv, tw, atol=2e-2, rtol=0)                                         # bf16 products vs fp32 torch
+        tv3, ti3 = K.lmhead_topk(h, emb, V, K2, bias=bias, beam_scores=bs, bans=bans, eos=2, suppress_eos=suppress)      # no logits output
+        assert torch.equal(ti3, ti) and torch.equal(tv3, tv)
+    # ties: equal columns -> lowest token ids first, banned ones skipped
+    embc = emb.clone(); embc[:] = embc[0]
+    tv4, ti4 = K.lmhead_topk(h, embc, V, 6, bans=torch.tensor([[1, 4]] * R, dtype=torch.int32).cuda(), eos=2, suppress_eos=True)
+    assert ti4.cpu().tolist() == [[0, 3, 5, 6, 7, 8]] * R
+    assert torch.allclose(tv4.cpu(), torch.full((R, 6), -math.log(V)), atol=1e-4)
+    # forced token: no logits at all; the forced token carries the beam score, the rest is -inf in token order
+    tv5, ti5 = K.lmhead_topk(h, emb, V, 4, beam_scores=bs, forced_token=2)
+    wv5, wi5 = K.beam_topk(logits, V, 4, beam_scores=bs, forced_token=2)
+    assert torch.equal(ti5, wi5) and torch.equal(tv5, wv5)
+    tv6, ti6 = K.lmhead_topk(h, emb, V, 4, beam_scores=bs, forced_token=0)
+    assert ti6.cpu().tolist() == [[0, 1, 2, 3]] * R and torch.equal(tv6[:, 0], bs)
 
 
 def test_cfg1_bart_base_vit_b32_only_image_full_depth_matches_oracle():

@@ -121,6 +121,11 @@ BeamState = _struct("vacnic_beam_state", [
     ("B", i64), ("nb", i64), ("Lmax", i64), ("V", i64), ("eos", i64), ("pad", i64), ("no_repeat_ngram_size", i64), ("early_stopping", i64),
     ("length_penalty", f32)])
 
+LmheadTopkArgs = _struct("vacnic_lmhead_topk_args", [
+    ("h", vp), ("emb", vp), ("bias", vp), ("logits", vp), ("workspace", vp), ("beam_scores", vp), ("bans", vp), ("top_val", vp), ("top_idx", vp),
+    ("R", i64), ("V", i64), ("d", i64), ("ldw", i64), ("ldl", i64), ("workspace_floats", i64),
+    ("n_ban", i32), ("eos", i32), ("suppress_eos", i32), ("forced_token", i32), ("K2", i32)])
+
 DecoderLayer = _struct("vacnic_decoder_layer", [
     ("w_kvq", vp), ("w_so", vp), ("w_cq", vp), ("w_co", vp), ("w_fc1", vp), ("w_fc2", vp),
     ("b_kvq", vp), ("b_so", vp), ("b_cq", vp), ("b_co", vp), ("b_fc1", vp), ("b_fc2", vp),
@@ -148,7 +153,7 @@ _STRUCT_FNS = {
     "vacnic_colam_fwd": ColamFwdArgs, "vacnic_colam_bwd": ColamBwdArgs,
     "vacnic_secla_fwd": SeclaFwdArgs, "vacnic_secla_bwd": SeclaBwdArgs,
     "vacnic_name_embed_mean": NameEmbedArgs, "vacnic_adamw": AdamwArgs, "vacnic_lmhead_ce_fwd": LmheadCeArgs,
-    "vacnic_decoder_step": DecoderStepArgs,
+    "vacnic_decoder_step": DecoderStepArgs, "vacnic_lmhead_topk": LmheadTopkArgs,
 }
 _PLAIN_FNS = {
     "vacnic_combine_losses": [vp, vp, vp, vp, f32, f32, vp, vp],
@@ -187,7 +192,8 @@ _PLAIN_FNS = {
 }
 EXPORTED = sorted(list(_STRUCT_FNS) + list(_PLAIN_FNS) + ["vacnic_last_error_string", "vacnic_version", "vacnic_decoder_step_sync_bytes", "vacnic_decoder_step_slots_bytes",
                                                             "vacnic_plan_begin", "vacnic_plan_size", "vacnic_plan_mark",
-                                                            "vacnic_gemm_workspace_bytes", "vacnic_gemm_counters", "vacnic_comm_init"])
+                                                            "vacnic_gemm_workspace_bytes", "vacnic_gemm_counters", "vacnic_comm_init",
+                                                            "vacnic_lmhead_topk_workspace"])
 
 for _name, _st in _STRUCT_FNS.items():
     _fn = getattr(lib, _name)          # AttributeError here = stale .so: fail loudly
@@ -211,6 +217,8 @@ lib.vacnic_plan_size.restype = C.c_int64
 lib.vacnic_plan_size.argtypes = [C.c_int64]
 lib.vacnic_plan_mark.restype = C.c_int64
 lib.vacnic_plan_mark.argtypes = []
+lib.vacnic_lmhead_topk_workspace.restype = C.c_int64
+lib.vacnic_lmhead_topk_workspace.argtypes = [C.c_int64, C.c_int64, C.c_int32]
 lib.vacnic_gemm_workspace_bytes.restype = C.c_int64
 lib.vacnic_gemm_workspace_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int64]
 lib.vacnic_gemm_counters.restype = C.c_int64

@@ -298,6 +298,254 @@ __global__ __launch_bounds__(TOPK_THREADS) void beam_topk_fast_kernel(const void
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// LM head + log_softmax + logits processors + top-K of the single-token decoder in TWO launches, without [R][V] logits in HBM
+// (MFULL:1997 lm_head + final_logits_bias; transformers 4.18 beam_search: log_softmax -> processors -> + beam_scores -> topk).
+// What it replaces per position: gemm_skinny (12.5 K one-wave workgroups, 2 loads in flight per lane: 35 us for 103 MB) + a
+// 5-workgroup top-k that reads the logits back twice (26 us).
+//   part kernel : G workgroups x 4 waves; a workgroup owns a contiguous range of <= 128 vocabulary columns and walks it in tiles of
+//                 16 columns.  The product is on the matrix cores (v_mfma_f32_16x16x32_bf16: A = 16 embedding rows, B = the hidden
+//                 rows, zero beyond R) — the VALU form (4 columns per wave like gemm_skinny, 8 rows) spends ~11 us per SIMD on
+//                 bf16 -> fp32 conversions and FMAs and was SLOWER than the chain it replaces (44 us).  The 4 waves split K (wave w
+//                 takes the 32-wide K steps w, w + 4, ...: 8 x 16-byte loads per lane and tile, the next TWO tiles in flight), their
+//                 partial tiles meet in LDS (one barrier per tile) and wave 0 finishes: + bias, an online (max, sum-exp) of the RAW
+//                 logits per lane, the masked logits (n-gram bans, suppressed EOS) into an LDS row buffer.  At the end one wave per
+//                 row picks the workgroup's K2 best under the order (score desc, token asc).
+//                 Output (field-major so that the merge reads contiguously): part[(r * (2 + 2 K2) + f) * G + g], f = max | sum-exp |
+//                 K2 values | K2 ids.
+//   merge kernel: one workgroup per row: log-sum-exp over the G partials, then K2 rounds of a workgroup-wide arg-best over the
+//                 G x K2 candidates (token ids are distinct, so "after the last pick" under the strict order excludes picks).
+// A forced token (ForcedBOS / ForcedEOS) needs neither logits nor lse: the merge kernel alone writes {forced: beam score, rest -inf}.
+constexpr int LT_MAXCOLS = 128;      // vocabulary columns per workgroup of the part kernel
+
+struct LmTopkP {
+  const bf16_t* h; const bf16_t* emb; const float* bias; float* logits; float* part;
+  const int* bans; const float* beam_scores; float* top_val; int* top_idx;
+  int R, V, K, ldw, ldl, n_ban, eos, suppress_eos, forced, K2, G, tpw;      // tpw: 16-column tiles per workgroup
+};
+
+template <int KS>                     // K steps (32 wide) per wave: K <= 128 * KS
+__global__ __launch_bounds__(256) void lmhead_part_kernel(LmTopkP p) {
+  __shared__ float sc[8][LT_MAXCOLS];                               // masked logits of this workgroup's columns
+  __shared__ unsigned banw[8][LT_MAXCOLS / 32];
+  __shared__ __attribute__((aligned(16))) float red[2][4][256];     // the 4 waves' partial tiles, double-buffered by tile parity
+  __shared__ float rm[64], rs[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 15, q = lane >> 4;
+  const int nst = (p.K + 31) >> 5;
+  const int t_lo = blockIdx.x * p.tpw, c_lo = t_lo * 16;
+  int ncol = p.V - c_lo;
+  if (ncol > p.tpw * 16) ncol = p.tpw * 16;
+  if (ncol < 0) ncol = 0;
+  const int t_hi = t_lo + ((ncol + 15) >> 4);
+  auto wload = [&](int t, u32x4 (&w)[KS]) {
+    const int n = t * 16 + col;
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+      const int k = (wave + 4 * i) * 32 + q * 8;
+      w[i] = (k < p.K && n < p.V) ? *(const u32x4*)(p.emb + (size_t)n * p.ldw + k) : (u32x4){0u, 0u, 0u, 0u};
+    }
+  };
+  // the first two tiles' weights are requested before anything else: they do not depend on the hidden rows
+  u32x4 wA[KS], wB[KS];
+  if (t_lo < t_hi) wload(t_lo, wA);
+  if (t_lo + 1 < t_hi) wload(t_lo + 1, wB);
+  bf16x8 xa[KS];                                                    // B operand: hidden row `col`, this wave's K steps
+#pragma unroll
+  for (int i = 0; i < KS; ++i) {
+    const int k = (wave + 4 * i) * 32 + q * 8;
+    const u32x4 v = (k < p.K && col < p.R) ? *(const u32x4*)(p.h + (size_t)col * p.K + k) : (u32x4){0u, 0u, 0u, 0u};
+    xa[i] = __builtin_bit_cast(bf16x8, v);
+  }
+  for (int i = tid; i < 8 * (LT_MAXCOLS / 32); i += 256) (&banw[0][0])[i] = 0u;
+  for (int i = tid; i < 8 * LT_MAXCOLS; i += 256) (&sc[0][0])[i] = -INFINITY;
+  __syncthreads();
+  if (p.bans) {
+    for (int i = tid; i < p.R * p.n_ban; i += 256) {
+      const int t = p.bans[i] - c_lo;
+      if (t >= 0 && t < ncol) atomicOr(&banw[i / p.n_ban][t >> 5], 1u << (t & 31));
+    }
+  }
+  if (p.suppress_eos && tid < p.R && p.eos >= c_lo && p.eos < c_lo + ncol) atomicOr(&banw[tid][(p.eos - c_lo) >> 5], 1u << ((p.eos - c_lo) & 31));
+  __syncthreads();
+  float mrun = -INFINITY, srun = 0.f;                               // wave 0, lanes with col < R: row `col`, columns q * 4 .. + 3 of every tile
+  const bool fin = wave == 0 && col < p.R;
+  auto tile = [&](u32x4 (&cur)[KS], int t, int par, int t_next) {
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (fin && p.bias) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int n = t * 16 + q * 4 + v;
+        if (n < p.V) bv[v] = p.bias[n];
+      }
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < KS; ++i)
+      if ((wave + 4 * i) < nst) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur[i]), xa[i], acc, 0, 0, 0);
+    if (t_next < t_hi) wload(t_next, cur);
+    *(f32x4*)&red[par][wave][lane * 4] = acc;
+    __syncthreads();
+    if (fin) {
+      const f32x4 s0 = *(const f32x4*)&red[par][0][lane * 4], s1 = *(const f32x4*)&red[par][1][lane * 4];
+      const f32x4 s2 = *(const f32x4*)&red[par][2][lane * 4], s3 = *(const f32x4*)&red[par][3][lane * 4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int n = t * 16 + q * 4 + v;
+        if (n < p.V) {
+          const float x = ((s0[v] + s1[v]) + s2[v]) + s3[v] + bv[v];
+          if (p.logits) p.logits[(size_t)col * p.ldl + n] = x;
+          const float nm = fmaxf(mrun, x);
+          srun = srun * __expf(mrun - nm) + __expf(x - nm);
+          mrun = nm;
+          const int j = n - c_lo;
+          sc[col][j] = (banw[col][j >> 5] >> (j & 31)) & 1u ? -INFINITY : x;
+        }
+      }
+    }
+  };
+  for (int t = t_lo; t < t_hi; t += 2) {
+    tile(wA, t, 0, t + 2);
+    if (t + 1 < t_hi) tile(wB, t + 1, 1, t + 3);
+  }
+  if (wave == 0) { rm[lane] = mrun; rs[lane] = srun; }
+  __syncthreads();
+  const int W = 2 + 2 * p.K2;
+  for (int r = wave; r < p.R; r += 4) {
+    float* out = p.part + (size_t)r * W * p.G + blockIdx.x;         // field f at out[f * G]
+    // log-sum-exp pieces of row r: wave 0's lanes r, r + 16, r + 32, r + 48
+    const float me = lane < 4 ? rm[r + 16 * lane] : -INFINITY;
+    const float se = lane < 4 ? rs[r + 16 * lane] : 0.f;
+    const float gm = wave_max(me);
+    const float tot = wave_sum(me == -INFINITY ? 0.f : se * __expf(me - gm));
+    if (lane == 0) { out[0] = gm; out[p.G] = tot; }
+    float cv[2]; int ci[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int j = lane + 64 * u;
+      cv[u] = j < ncol ? sc[r][j] : -INFINITY;
+      ci[u] = j < ncol ? c_lo + j : 0x7fffffff;
+    }
+    for (int k = 0; k < p.K2; ++k) {
+      float bv = cv[0]; int bi = ci[0];
+      if (cv[1] > bv || (cv[1] == bv && ci[1] < bi)) { bv = cv[1]; bi = ci[1]; }
+      wave_argbest(bv, bi);
+      if (bi != 0x7fffffff) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          if (ci[u] == bi) { cv[u] = -INFINITY; ci[u] = 0x7fffffff; }
+      }
+      if (lane == 0) {
+        const bool none = bi == 0x7fffffff || bv == -INFINITY;       // banned / missing columns never become candidates
+        out[(size_t)(2 + k) * p.G] = none ? -INFINITY : bv;
+        ((int*)out)[(size_t)(2 + p.K2 + k) * p.G] = none ? 0x7fffffff : bi;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void lmhead_merge_kernel(LmTopkP p) {
+  extern __shared__ __attribute__((aligned(16))) char lt_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = blockIdx.x, K2 = p.K2, W = 2 + 2 * K2, G = p.G;
+  const float base = p.beam_scores ? p.beam_scores[r] : 0.f;
+  if (p.forced >= 0) {
+    // ForcedBOS / ForcedEOS: the forced token scores `base`, everything else -inf in token order (beam_topk_kernel's result)
+    if (tid < K2) {
+      const int rest = tid - 1 + (tid - 1 >= p.forced ? 1 : 0);
+      p.top_val[(size_t)r * K2 + tid] = tid == 0 ? base : -INFINITY;
+      p.top_idx[(size_t)r * K2 + tid] = tid == 0 ? p.forced : (rest < p.V ? rest : -1);
+    }
+    return;
+  }
+  float* cand_v = (float*)lt_smem;                 // [K2][G]
+  int* cand_i = (int*)(cand_v + (size_t)G * K2);
+  __shared__ float rv[4]; __shared__ int ri[4]; __shared__ float red[4];
+  const float* prow = p.part + (size_t)r * W * G;  // this row's fields, each G contiguous floats
+  // every load of the kernel is issued before the first is consumed (they come from another kernel's stores: ~2 us a round trip;
+  // batches of 8 made this kernel five round trips = 15 us long): the log-sum-exp pieces, then the candidates 40 per thread
+  float mloc[4], sloc[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int g = tid + 256 * u;
+    mloc[u] = g < G ? prow[g] : -INFINITY;
+    sloc[u] = g < G ? prow[G + g] : 0.f;
+  }
+  const int n = G * K2;
+  for (int e0 = tid; e0 < 2 * n; e0 += 256 * 40) {
+    unsigned x[40];
+#pragma unroll
+    for (int u = 0; u < 40; ++u) {
+      const int e = e0 + 256 * u;
+      x[u] = e < 2 * n ? ((const unsigned*)prow)[2 * G + e] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 40; ++u) {
+      const int e = e0 + 256 * u;
+      if (e < 2 * n) ((unsigned*)lt_smem)[e] = x[u];          // values then ids: the same [field][g] order as in HBM
+    }
+  }
+  // ---- log-sum-exp over the workgroups' pieces (fixed order: thread-strided, then wave butterflies, then 4 waves in order)
+  float mt = fmaxf(fmaxf(mloc[0], mloc[1]), fmaxf(mloc[2], mloc[3]));
+  for (int g = tid + 1024; g < G; g += 256) mt = fmaxf(mt, prow[g]);
+  mt = wave_max(mt);
+  if (lane == 0) red[wave] = mt;
+  __syncthreads();
+  const float gm = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float st = 0.f;
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+    if (mloc[u] != -INFINITY) st += sloc[u] * __expf(mloc[u] - gm);
+  for (int g = tid + 1024; g < G; g += 256) {
+    const float me = prow[g];
+    if (me != -INFINITY) st += prow[G + g] * __expf(me - gm);
+  }
+  st = wave_sum(st);
+  if (lane == 0) red[wave] = st;
+  __syncthreads();
+  const float lse = gm + logf(((red[0] + red[1]) + red[2]) + red[3]);
+  // ---- K2 picks.  Every workgroup's list is sorted (score desc, token asc), so only list HEADS compete: a thread keeps the heads of
+  // its (<= 2) lists in registers, a round is one workgroup-wide arg-best over them and the winner steps to its list's next entry.
+  // (Scanning all G x K2 candidates per round — 18 dependent LDS round trips per thread — cost 40 us.)
+  float hv[2]; int hi[2], hp[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int g = tid + 256 * u;
+    hp[u] = 0;
+    hv[u] = g < G ? cand_v[g] : -INFINITY;
+    hi[u] = g < G ? cand_i[g] : 0x7fffffff;
+  }
+  for (int k = 0; k < K2; ++k) {
+    float bv = hv[0]; int bi = hi[0];
+    if (hi[1] != 0x7fffffff && (bi == 0x7fffffff || hv[1] > bv || (hv[1] == bv && hi[1] < bi))) { bv = hv[1]; bi = hi[1]; }
+    if (bi == 0x7fffffff) bv = -INFINITY;
+    wave_argbest(bv, bi);
+    __syncthreads();
+    if (lane == 0) { rv[wave] = bv; ri[wave] = bi; }
+    __syncthreads();
+    bv = rv[0]; bi = ri[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+      if (rv[w] > bv || (rv[w] == bv && ri[w] < bi)) { bv = rv[w]; bi = ri[w]; }
+    if (tid == 0) {
+      const bool none = bi == 0x7fffffff;
+      p.top_val[(size_t)r * K2 + k] = none ? -INFINITY : bv - lse + base;
+      p.top_idx[(size_t)r * K2 + k] = none ? -1 : bi;
+    }
+    if (bi != 0x7fffffff) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (hi[u] == bi) {                             // this thread's list won: its next entry becomes the head
+          const int g = tid + 256 * u;
+          ++hp[u];
+          hv[u] = hp[u] < K2 ? cand_v[hp[u] * G + g] : -INFINITY;
+          hi[u] = hp[u] < K2 ? cand_i[hp[u] * G + g] : 0x7fffffff;
+        }
+    }
+  }
+}
+
 // dst[r][:row_bytes] = src[g][:row_bytes], g = idx[r] (period == 0) or (r / period) * period + idx[r % period] (the same beam
 // permutation applied to every layer's block of `period` rows); rows are `stride` 16-byte chunks apart, `chunks` of them copied
 __global__ __launch_bounds__(256) void gather_rows_kernel(const char* __restrict__ src, char* __restrict__ dst,
@@ -331,16 +579,18 @@ struct BeamP {
   float length_penalty;
 };
 
-__global__ __launch_bounds__(64) void beam_step_kernel(BeamP p) {
-  const int b = blockIdx.x, lane = threadIdx.x;
+// One workgroup per batch item, one wave per beam: wave 0 merges the candidates and does BeamSearchScorer.process, then wave j
+// writes beam j's history / score / source row and its ban list (one global round trip per beam in parallel instead of 2 nb in a row).
+__global__ __launch_bounds__(1024) void beam_step_kernel(BeamP p) {
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nthr = blockDim.x;
   const int nb = p.nb, K2 = p.K2, L = p.Lmax, cur = p.cur_len;
   __shared__ float cs[64]; __shared__ int cj[64], ct[64];          // the group's top-2nb candidates, in rank order
   __shared__ float nsc[32]; __shared__ int ntok[32], nsrc[32];      // the nb continuing beams
   __shared__ int hyp_from[288]; __shared__ int hyp_slot[288]; __shared__ int n_hyp_copy;   // <= nb adds x (nb - 1 shifts + 1) per position
   __shared__ int is_done, nsel_s;
-  if (lane == 0) { n_hyp_copy = 0; is_done = p.done[b]; nsel_s = 0; }
+  if (tid == 0) { n_hyp_copy = 0; is_done = p.done[b]; nsel_s = 0; }
   __syncthreads();
-  if (!is_done) {
+  if (!is_done && wv == 0) {
     // ---- merge the per-beam top-2nb lists: order (score desc, beam * V + token asc), keep 2nb.  Every lane owns up to two
     // candidates; each round is a wave-wide arg-best by shuffles (a serial scan by one lane over global memory cost ~0.8 ms).
     const int ncand = nb * K2;
@@ -385,7 +635,7 @@ __global__ __launch_bounds__(64) void beam_step_kernel(BeamP p) {
     }
   }
   __syncthreads();
-  if (lane == 0) {
+  if (tid == 0) {
     if (!is_done) {
       const int nsel = nsel_s;
       // ---- BeamSearchScorer.process: EOS candidates within the first nb ranks finish a hypothesis, the rest continue
@@ -445,46 +695,47 @@ __global__ __launch_bounds__(64) void beam_step_kernel(BeamP p) {
     const int from = hyp_from[c], slot = hyp_slot[c];
     const int32_t* src = from < 0 ? p.hyp_seq + ((size_t)b * nb + (-from - 1)) * L : p.seq_in + (size_t)from * L;
     int32_t* dst = p.hyp_seq + ((size_t)b * nb + slot) * L;
-    int32_t tmp[8];                                     // L <= 512
+    int32_t tmp[8];                                     // L <= 512, >= 64 threads
     int n = 0;
-    for (int i = lane; i < L; i += 64) tmp[n++] = src[i];
+    for (int i = tid; i < L; i += nthr) tmp[n++] = src[i];
     __syncthreads();
     n = 0;
-    for (int i = lane; i < L; i += 64) dst[i] = tmp[n++];
+    for (int i = tid; i < L; i += nthr) dst[i] = tmp[n++];
     __syncthreads();
   }
-  // ---- the nb continuing beams: history + new token, score, source row, last token; then their NoRepeatNGram bans
-  for (int j = 0; j < nb; ++j) {
-    const int row = b * nb + j;
+  // ---- the nb continuing beams, one wave each: history + new token (kept in LDS for the ban search), score, source row, last
+  // token; then the NoRepeatNGram bans of the next position
+  __shared__ int sseq[16][512];
+  __shared__ int nban[16];
+  if (wv < nb) {
+    const int j = wv, row = b * nb + j;
     const int32_t* src = p.seq_in + (size_t)nsrc[j] * L;
     int32_t* dst = p.seq_out + (size_t)row * L;
-    for (int i = lane; i < L; i += 64) dst[i] = i < cur ? src[i] : (i == cur ? ntok[j] : p.pad);
+    if (lane == 0) nban[j] = 0;
+    for (int i = lane; i < L; i += 64) {
+      const int v = i < cur ? src[i] : (i == cur ? ntok[j] : p.pad);
+      dst[i] = v;
+      sseq[j][i] = v;
+    }
     if (lane == 0) {
       p.beam_scores[row] = nsc[j];
       p.next_ids[row] = ntok[j];
       p.src_idx[row] = nsrc[j];
     }
-  }
-  __syncthreads();
-  if (p.bans) {
-    const int n = p.ngram, len = cur + 1;                 // histories now hold cur + 1 tokens
-    __shared__ int nban;
-    for (int j = 0; j < nb; ++j) {
-      const int row = b * nb + j;
-      const int32_t* sq = p.seq_out + (size_t)row * L;
+    if (p.bans) {
+      // (a wave's LDS operations execute in order: the history written above is visible to all its lanes here)
+      const int n = p.ngram, len = cur + 1;               // histories now hold cur + 1 tokens
+      const int* sq = sseq[j];
       int32_t* bn = p.bans + (size_t)row * L;
-      if (lane == 0) nban = 0;
-      __syncthreads();
       if (n > 0 && len + 1 >= n && !is_done) {
         for (int i = lane; i <= len - n; i += 64) {
           bool match = true;
           for (int k = 0; k < n - 1; ++k) match = match && sq[i + k] == sq[len - (n - 1) + k];
-          if (match) bn[atomicAdd(&nban, 1)] = sq[i + n - 1];
+          if (match) bn[atomicAdd(&nban[j], 1)] = sq[i + n - 1];
         }
       }
-      __syncthreads();
-      for (int i = nban + lane; i < L; i += 64) bn[i] = -1;
-      __syncthreads();
+      const int nb_ = nban[j];
+      for (int i = nb_ + lane; i < L; i += 64) bn[i] = -1;
     }
   }
 }
@@ -526,6 +777,57 @@ extern "C" int vacnic_beam_topk(const void* logits, const float* beam_scores, co
   else
     hipLaunchKernelGGL(beam_topk_kernel<false>, dim3((unsigned)R), dim3(256), 0, s, logits, beam_scores, bans, n_ban, eos,
                        suppress_eos, forced_token, top_val, top_idx, (int)V, (long)ldl, K);
+  VLAUNCH_CHECK();
+  return VACNIC_OK;
+}
+
+static int lt_tiles_per_wg(int64_t V) {
+  const int64_t nt = (V + 15) / 16;
+  int64_t tpw = (nt + 511) / 512;                  // at most 512 workgroups (two per CU), all of them with the same number of tiles
+  if (tpw < 1) tpw = 1;
+  static const char* dbg = getenv("VACNIC_LT_TPW");    // measurement aid (tools/bench_lmhead_topk.py): tiles per workgroup, >= the default
+  if (dbg && atoi(dbg) >= tpw && atoi(dbg) * 16 <= LT_MAXCOLS) tpw = atoi(dbg);
+  return (int)tpw;
+}
+
+extern "C" int64_t vacnic_lmhead_topk_workspace(int64_t R, int64_t V, int32_t K2) {
+  if (R <= 0 || V <= 0 || K2 <= 0) return 0;
+  const int tpw = lt_tiles_per_wg(V);
+  const int64_t G = ((V + 15) / 16 + tpw - 1) / tpw;
+  return G * R * (2 + 2 * (int64_t)K2);
+}
+
+extern "C" int vacnic_lmhead_topk(const vacnic_lmhead_topk_args* a, void* stream) {
+  VPLAN_REC_STRUCT(vacnic_lmhead_topk, a, stream);
+  VCHECK(a && a->top_val && a->top_idx, VACNIC_BAD_SHAPE, "lmhead_topk: null operand");
+  VCHECK(a->R >= 1 && a->R <= 8 && a->V > 0 && a->K2 >= 1 && a->K2 <= 64 && a->K2 <= a->V, VACNIC_UNSUPPORTED, "lmhead_topk: 1 <= R <= 8, 1 <= K2 <= min(64, V)");
+  LmTopkP p;
+  p.h = (const bf16_t*)a->h; p.emb = (const bf16_t*)a->emb; p.bias = a->bias; p.logits = a->logits; p.part = a->workspace;
+  p.bans = a->bans; p.beam_scores = a->beam_scores; p.top_val = a->top_val; p.top_idx = a->top_idx;
+  p.R = (int)a->R; p.V = (int)a->V; p.K = (int)a->d; p.ldw = (int)a->ldw; p.ldl = (int)a->ldl; p.n_ban = a->bans ? a->n_ban : 0;
+  p.eos = a->eos; p.suppress_eos = a->suppress_eos; p.forced = a->forced_token; p.K2 = a->K2;
+  p.tpw = lt_tiles_per_wg(a->V);
+  p.G = (int)(((a->V + 15) / 16 + p.tpw - 1) / p.tpw);
+  hipStream_t s = (hipStream_t)stream;
+  if (a->forced_token >= 0) {
+    VCHECK(a->forced_token < a->V, VACNIC_BAD_SHAPE, "lmhead_topk: forced token outside the vocabulary");
+    VCHECK(!a->logits, VACNIC_UNSUPPORTED, "lmhead_topk: a forced position computes no logits (pass logits = NULL)");
+    hipLaunchKernelGGL(lmhead_merge_kernel, dim3((unsigned)a->R), dim3(256), 0, s, p);
+    VLAUNCH_CHECK();
+    return VACNIC_OK;
+  }
+  VCHECK(a->h && a->emb && a->workspace, VACNIC_BAD_SHAPE, "lmhead_topk: null operand");
+  VCHECK(a->d >= 8 && a->d <= 1024 && (a->d & 7) == 0 && a->ldw >= a->d && (a->ldw & 7) == 0 && aligned16(a->h) && aligned16(a->emb), VACNIC_UNSUPPORTED,
+         "lmhead_topk: d_model <= 1024, a multiple of 8, 16-byte aligned rows");
+  VCHECK(p.tpw * 16 <= LT_MAXCOLS, VACNIC_UNSUPPORTED, "lmhead_topk: vocabulary above %d columns", 512 * LT_MAXCOLS);
+  VCHECK(!a->logits || a->ldl >= a->V, VACNIC_BAD_SHAPE, "lmhead_topk: ldl < V");
+  VCHECK(a->workspace_floats >= vacnic_lmhead_topk_workspace(a->R, a->V, a->K2), VACNIC_BAD_SHAPE, "lmhead_topk: workspace of %ld floats, need %ld",
+         (long)a->workspace_floats, (long)vacnic_lmhead_topk_workspace(a->R, a->V, a->K2));
+  if (a->d > 256) hipLaunchKernelGGL(lmhead_part_kernel<8>, dim3((unsigned)p.G), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(lmhead_part_kernel<2>, dim3((unsigned)p.G), dim3(256), 0, s, p);
+  VLAUNCH_CHECK();
+  const size_t lds_merge = (size_t)p.G * a->K2 * 8;
+  hipLaunchKernelGGL(lmhead_merge_kernel, dim3((unsigned)a->R), dim3(256), lds_merge, s, p);
   VLAUNCH_CHECK();
   return VACNIC_OK;
 }
@@ -576,7 +878,7 @@ extern "C" int vacnic_beam_step(const vacnic_beam_state* st, const float* top_va
   p.hyp_len = st->hyp_len; p.hyp_seq = st->hyp_seq; p.next_ids = st->next_ids; p.src_idx = st->src_idx; p.bans = st->bans;
   p.nb = (int)st->nb; p.K2 = K2; p.Lmax = (int)st->Lmax; p.cur_len = cur_len; p.V = (int)st->V; p.eos = (int)st->eos; p.pad = (int)st->pad;
   p.ngram = (int)st->no_repeat_ngram_size; p.early = (int)st->early_stopping; p.length_penalty = st->length_penalty;
-  hipLaunchKernelGGL(beam_step_kernel, dim3((unsigned)st->B), dim3(64), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(beam_step_kernel, dim3((unsigned)st->B), dim3((unsigned)(64 * st->nb)), 0, (hipStream_t)stream, p);
   VLAUNCH_CHECK();
   return VACNIC_OK;
 }

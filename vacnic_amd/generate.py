@@ -224,8 +224,9 @@ class CachedDecoder:
             raise RuntimeError("vacnic_decoder_step: a wait inside the step kernel timed out (workgroups not co-resident?); results of "
                                "this caption are invalid; this decoder falls back to the kernel-per-op chain")
 
-    def step(self, ids_t, t):
-        """ids_t int64 [rows, 1] (token at position t) -> fp32 logits [rows, V_pad]."""
+    def step(self, ids_t, t, hidden_only=False):
+        """ids_t int64 [rows, 1] (token at position t) -> fp32 logits [rows, V_pad]; hidden_only: the decoder's final hidden rows
+        [rows, d] (bf16, after the last layer's LayerNorm) instead — the input of kernels.lmhead_topk."""
         m, dec, d, H, R = self.m, self.dec, self.d, self.H, self.rows
         ln = dec.layernorm_embedding
         h, _, _ = K.embed_ln_fwd(ids_t, dec.embed_tokens.weight.w16, dec.embed_positions.weight.w16, ln.weight.data, ln.bias.data,
@@ -281,6 +282,16 @@ class CachedDecoder:
                 pend, pend_ln = (o, h), layer.final_layer_norm
             else:
                 h, _, _ = K.add_ln_fwd(o.view(R, 1, d), h, layer.final_layer_norm.weight.data, layer.final_layer_norm.bias.data, need_stats=False)
+        if hidden_only:
+            if self.step_kernel and self.slots is not None:
+                self.last_hidden = pend[0]
+            elif fuse and pend is not None:
+                o_, res_ = pend
+                hn, _, _ = K.add_ln_fwd(o_.view(R, 1, d), res_.view(R, 1, d), pend_ln.weight.data, pend_ln.bias.data, need_stats=False)
+                self.last_hidden = hn.view(R, d)
+            else:
+                self.last_hidden = h.view(R, d)
+            return self.last_hidden
         logits = torch.empty((R, m.V_pad), device=h.device, dtype=torch.float32)
         # last_hidden: the final hidden rows [R, d] behind these logits (diagnostics / fixture construction; overwritten every step)
         if self.step_kernel and self.slots is not None:     # slot variant: obuf already holds the final (normalised) hidden rows
@@ -325,6 +336,9 @@ class DecodeSession:
         self.h_src = torch.zeros(R, dtype=torch.long).pin_memory()
         self.h_bans = torch.full((R, max_length), -1, dtype=torch.int32).pin_memory() if ngram > 0 else None
         self.graphs, self.outs, self.pool = {}, {}, None
+        # few rows (one caption's beams): the fused LM head + top-k (VACNIC_FUSED_LMHEAD_TOPK=0: skinny GEMM -> vacnic_beam_topk)
+        self.fused_tail = (R <= 8 and model.emb16_pad.shape[1] <= 1024 and model.emb16_pad.shape[1] % 8 == 0 and min(2 * nb, model.V) <= 64
+                           and model.V <= 512 * 128 and os.environ.get("VACNIC_FUSED_LMHEAD_TOPK", "1") != "0")
         self.captions = 0
         self.beam = None                  # device-side beam bookkeeping (enable_device_beams)
 
@@ -396,14 +410,21 @@ class DecodeSession:
     def body(self, t):
         if self.nb > 1 and t > 0:
             self.dec.reorder(self.src_s, t)
-        logits = self.dec.step(self.ids_s, t)
         cur_len = t + 1
         forced = self.forced_eos if (self.forced_eos is not None and cur_len == self.max_length - 1) else -1
         if self.forced_bos is not None and cur_len == 1:             # ForcedBOSTokenLogitsProcessor (runs before ForcedEOS in HF)
             forced = self.forced_bos if forced < 0 else forced
         V = self.model.V
-        tv, ti = K.beam_topk(logits, V, min(2 * self.nb, V), beam_scores=self.scores_s, bans=self.bans_s, eos=self.eos,
-                             suppress_eos=cur_len < self.min_length, forced_token=forced)
+        if self.fused_tail:
+            # LM head + log_softmax + processors + top-2nb in one C call, no [R, V] logits (a forced position needs no LM head at all)
+            hid = self.dec.step(self.ids_s, t, hidden_only=True)
+            tv, ti = K.lmhead_topk(hid, self.model.emb16_pad, V, min(2 * self.nb, V), bias=self.model.final_logits_bias.view(-1),
+                                   beam_scores=self.scores_s, bans=self.bans_s, eos=self.eos, suppress_eos=cur_len < self.min_length,
+                                   forced_token=forced)
+        else:
+            logits = self.dec.step(self.ids_s, t)
+            tv, ti = K.beam_topk(logits, V, min(2 * self.nb, V), beam_scores=self.scores_s, bans=self.bans_s, eos=self.eos,
+                                 suppress_eos=cur_len < self.min_length, forced_token=forced)
         if self.beam is not None:
             from . import _lib
             _lib.check(_lib.lib.vacnic_beam_step(_lib.C.byref(self.beam), tv.data_ptr(), ti.data_ptr(), tv.shape[1], cur_len, K._stream()))

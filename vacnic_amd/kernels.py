@@ -153,6 +153,7 @@ _load_tuned()
 _TUNED_FIXUP = __import__("os").environ.get("VACNIC_GEMM_FIXUP_TUNED", "1") != "0"      # A/B: 0 = ignore the fix-up entries of gemm_tuned.json
 _FIX = {}                 # launch stream -> [workspace (uint8), counters (int32, all zero between launches)]
 _FIX_CAPTURE = {}         # the same for launches recorded by a hipGraph capture on that stream (buffers from the graph's private pool)
+_FIX_CAPTURE_FLOOR = 0    # bytes (a debugging aid: tools/enc_graph_check.py)
 _FIX_OLD = []             # outgrown workspaces: kernels already enqueued may still use them
 
 
@@ -168,7 +169,7 @@ def _fix_buffers(stream, M, N, split_k):
     table = _FIX_CAPTURE if torch.cuda.is_current_stream_capturing() else _FIX
     ent = table.get(stream)
     if ent is None or ent[0].numel() < need or ent[1].numel() < ncnt:
-        floor = 0 if table is _FIX_CAPTURE else 64 << 20
+        floor = _FIX_CAPTURE_FLOOR if table is _FIX_CAPTURE else 64 << 20
         ws = torch.empty(max(need, ent[0].numel() if ent else 0, floor), device="cuda", dtype=torch.uint8)
         cnt = torch.empty(max(ncnt, ent[1].numel() if ent else 0, 4096), device="cuda", dtype=torch.int32)
         call("vacnic_zero_bytes", cnt.data_ptr(), cnt.numel() * 4, stream)
@@ -628,6 +629,22 @@ def beam_topk(logits, V, K_, beam_scores=None, bans=None, eos=2, suppress_eos=Fa
     ti = torch.empty((R, K_), device=logits.device, dtype=torch.int32)
     call("vacnic_beam_topk", _p(logits), _p(beam_scores), _p(bans), bans.shape[1] if bans is not None else 0, eos, int(suppress_eos),
          forced_token, _p(tv), _p(ti), R, V, logits.stride(0), K_, int(logits.dtype == torch.float32), _stream())
+    return tv, ti
+
+
+def lmhead_topk(h, emb, V, K_, *, bias=None, beam_scores=None, bans=None, eos=2, suppress_eos=False, forced_token=-1, logits=None):
+    """(top values, top ids) [R, K_] of log_softmax(h . emb[:V]^T + bias) after the logits processors, + beam_scores — the LM head
+    and vacnic_beam_topk of one decode position without the [R, V] logits (R <= 8, d_model <= 1024).  A forced position
+    (forced_token >= 0) computes no logits at all.  logits: optional fp32 [R, >= V] buffer that receives them (diagnostics)."""
+    R, d = h.shape
+    tv = torch.empty((R, K_), device=h.device, dtype=torch.float32)
+    ti = torch.empty((R, K_), device=h.device, dtype=torch.int32)
+    nws = int(_lib.lib.vacnic_lmhead_topk_workspace(R, V, K_)) if forced_token < 0 else 0
+    ws = torch.empty(nws, device=h.device, dtype=torch.float32) if nws else None
+    call_struct("vacnic_lmhead_topk", stream=_stream(), h=_p(h), emb=_p(emb), bias=_p(bias), logits=_p(logits) if forced_token < 0 else None,
+                workspace=_p(ws), beam_scores=_p(beam_scores), bans=_p(bans), top_val=_p(tv), top_idx=_p(ti), R=R, V=V, d=d, ldw=emb.stride(0),
+                ldl=logits.stride(0) if logits is not None else 0, workspace_floats=nws, n_ban=bans.shape[1] if bans is not None else 0, eos=eos,
+                suppress_eos=int(suppress_eos), forced_token=forced_token, K2=K_)
     return tv, ti
 
 
