@@ -368,6 +368,41 @@ def test_greedy_decode_ids_match_oracle():
     assert torch.equal(got.cpu(), want), (got.cpu(), want)
 
 
+def test_caption_pipeline_matches_the_sequential_generation_loop():
+    """gen_caption_from_loader_bart (TRAIN:480-530) with the two-stage pipeline (caption i + 1's image tower, encoder and cross K/V
+    on a side stream during caption i's beam search) against the plain loop: same ids for every caption — batch 1 (staged encoder
+    side) and batch 2 (plain generate with the image tower ahead), five captions each so that staging buffers, graph replays and
+    the per-position decode graphs are all reused."""
+    from vacnic_amd import synthetic
+    from vacnic_amd.config import ClipVisionConfig
+    from vacnic_amd.training import build_models, gen_caption_from_loader_bart
+    cfg = small_cfg(encoder_layers=2, decoder_layers=2, enc_fusion_layer=[0, 1], clip_width=128)
+    vcfg = ClipVisionConfig(width=128, layers=2, patch_size=16, image_size=32, output_dim=64)
+    model, _, _ = build_models(cfg, vcfg, init="synthetic", seed=5)
+    for B in (1, 2):
+        batches = [synthetic.make_batch(cfg, B, S=24, T=8, F=2, seed=70 + i, image_size=32) for i in range(5)]
+        kw = dict(min_length=5, no_repeat_ngram_size=2)
+        plain = gen_caption_from_loader_bart(model, batches, 3, 10, length_penalty=2.0, pipeline=False, **kw)
+        piped = gen_caption_from_loader_bart(model, batches, 3, 10, length_penalty=2.0, pipeline=True, **kw)
+        again = gen_caption_from_loader_bart(model, batches[::-1], 3, 10, length_penalty=2.0, pipeline=True, **kw)
+        assert len(piped) == len(plain) == 5
+        for i in range(5):
+            assert piped[i]["gen"] == plain[i]["gen"], (B, i, piped[i]["gen"], plain[i]["gen"])
+            assert again[4 - i]["gen"] == plain[i]["gen"], (B, i)
+        if B == 1:
+            # random-init weights write the same caption for every input, so also look at what the decoder was given: after a pipelined
+            # pass the live cross-attention K/V are bit for bit those of the LAST caption (as a sequential call computes them), not the
+            # previous one's
+            ses = [v for v in model._decode_sessions.values() if v.dec.rows == 3][-1]
+            gen_caption_from_loader_bart(model, batches, 3, 10, length_penalty=2.0, pipeline=True, **kw)
+            live = ses.dec.cross_all[:, 0].clone()
+            gen_caption_from_loader_bart(model, batches[4:], 3, 10, length_penalty=2.0, pipeline=False, **kw)
+            last = ses.dec.cross_all[:, 0].clone()
+            gen_caption_from_loader_bart(model, batches[3:4], 3, 10, length_penalty=2.0, pipeline=False, **kw)
+            prev = ses.dec.cross_all[:, 0].clone()
+            assert torch.equal(live, last) and not torch.equal(live, prev)
+
+
 GEN_CASES = [(5, 2.0, {}), (5, 1.0, {}), (1, 1.0, dict(min_length=4)), (5, 1.0, dict(min_length=4)),
              (4, 2.0, dict(min_length=3, no_repeat_ngram_size=2)), (3, 0.5, dict(min_length=5, no_repeat_ngram_size=3, early_stopping=True)),
              # the generation defaults of the facebook/bart-* hub checkpoints (config.HUB_GENERATION_DEFAULTS) at config 5's beam / length penalty

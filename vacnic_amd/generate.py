@@ -131,7 +131,8 @@ class CachedDecoder:
         self.cache = [torch.zeros((self.L, rows, max_length + 1, 2 * d), device=dev, dtype=BF16) for _ in range(2 if reorders else 1)]
         self.enc_b = torch.empty((rows, S, d), device=dev, dtype=BF16)
         self.enc_mask = torch.empty((rows, S), device=dev, dtype=torch.uint8)
-        self.cross = [torch.empty((rows, S, 2 * d), device=dev, dtype=BF16) for _ in range(self.L)]
+        self.cross_all = torch.empty((self.L, rows, S, 2 * d), device=dev, dtype=BF16)      # one block: a staged caption arrives in one copy
+        self.cross = [self.cross_all[li] for li in range(self.L)]
         self.lidx = (torch.arange(self.L, device=dev)[:, None] * rows).contiguous()
         # persistent decoder-step kernel (vacnic_decoder_step): all layers of a position in one launch.  VACNIC_DECODE_PER_OP=1
         # keeps the kernel-per-op chain (the reference the step kernel is tested against).
@@ -169,6 +170,16 @@ class CachedDecoder:
         for li, layer in enumerate(self.dec.layers):
             a = layer.encoder_attn
             K.gemm(src.reshape(M, d), a.s_kv.w16, M, 2 * d, d, bias=a.s_kv.bias, out=self.cross[li].view(self.rows * S, 2 * d)[:M])
+
+    def begin_staged(self, stage):
+        """begin() for a caption whose encoder side ran ahead of time (EncodeStage, B == 1): the cross-attention K/V of every layer
+        and the key mask are copied from the staging buffers (24 MB device to device at BART-large: ~15 us)."""
+        if self.rows != stage.nb or self.S != stage.S:
+            raise ValueError("begin_staged: the stage was encoded for another decode shape")
+        self.shared_kv = True
+        S, d = self.S, self.d
+        K.copy3d(stage.cross_all, self.cross_all[:, 0], self.L, S, 2 * d)
+        self.enc_mask.copy_(stage.mask.expand(self.rows, S))
 
     def cache_at(self, t):
         return self.cache[t & 1] if self.reorders else self.cache[0]
@@ -464,11 +475,120 @@ class DecodeSession:
         return tv, ti
 
 
+def _run_encoder(model, use_graphs, add_ner_ffn, input_ids, mask_u8, image_features, name_ids, name_mask, face_features, face_mask):
+    """the encoder pass of one generate() call: a hipGraph per input signature (GraphedCall) unless use_graphs is off"""
+    def run_encoder(ids, m8, img, nids, nmask, faces, fmask, add_ner_ffn=add_ner_ffn):
+        return model.model.encoder(input_ids=ids, attention_mask=m8, image_features=img, name_ids=nids, name_mask=nmask,
+                                   face_features=faces, face_mask=fmask, add_ner_ffn=add_ner_ffn)["last_hidden_state"]
+    if not use_graphs:
+        return run_encoder(input_ids, mask_u8, image_features, name_ids, name_mask, face_features, face_mask)
+    ge = model.__dict__.setdefault("_graphed_encoders", {})
+    if add_ner_ffn not in ge:
+        ge[add_ner_ffn] = GraphedCall(run_encoder)
+    return ge[add_ner_ffn](input_ids, mask_u8, image_features, name_ids, name_mask, face_features, face_mask)
+
+
+class EncodeStage:
+    """Everything the beam search of ONE caption (B == 1) needs from the encoder side, in buffers of its own: the cross-attention K/V
+    of every decoder layer and the source key mask.  Filled by encode() on whatever stream is current — CaptionPipeline runs it on
+    a side stream for caption i + 1 while caption i is being decoded — and consumed by generate(encoded=stage)."""
+
+    def __init__(self, model, S, nb):
+        dec = model.model.decoder
+        d = model.config.d_model
+        dev = model.emb16_pad.device
+        self.S, self.d, self.nb = S, d, nb
+        self.cross_all = torch.empty((len(dec.layers), S, 2 * d), device=dev, dtype=BF16)
+        self.cross = [self.cross_all[li] for li in range(len(dec.layers))]
+        self.mask = torch.empty((1, S), device=dev, dtype=torch.uint8)
+
+    @torch.no_grad()
+    def encode(self, model, input_ids, attention_mask, image_features=None, face_features=None, face_mask=None, name_ids=None, name_mask=None,
+               add_ner_ffn=True, use_graphs=True):
+        if input_ids.shape[0] != 1 or input_ids.shape[1] != self.S:
+            raise ValueError("EncodeStage.encode: one caption of the staged source length")
+        mask_u8 = attention_mask.to(torch.uint8) if attention_mask.dtype != torch.uint8 else attention_mask
+        enc_h = _run_encoder(model, use_graphs, add_ner_ffn, input_ids, mask_u8, image_features, name_ids, name_mask, face_features, face_mask)
+        S, d = self.S, self.d
+        for li, layer in enumerate(model.model.decoder.layers):
+            a = layer.encoder_attn
+            K.gemm(enc_h.reshape(S, d), a.s_kv.w16, S, 2 * d, d, bias=a.s_kv.bias, out=self.cross[li])
+        self.mask.copy_(mask_u8)
+        return self
+
+
+class CaptionPipeline:
+    """model.generate over a stream of single captions (test_batch_size 1, the reference's generation loop TRAIN:480-530) as a
+    two-stage pipeline: the image tower, the encoder and the cross-attention K/V projection of caption i + 1 are enqueued on a side
+    stream BEFORE the beam search of caption i is — they do not depend on it, and the beam search is a chain of latency-bound
+    launches that leaves most of the GPU idle.  Same ids as the sequential loop (the kernels are the same, only their streams
+    differ).  `inputs_fn(batch)` -> (input_ids, attention_mask, image_features, kw) builds the masks and runs the image tower
+    (training._model_inputs); it is called under the side stream.  Batches with more than one caption take the plain path."""
+
+    def __init__(self, model, inputs_fn, num_beams, **gen_kw):
+        self.model, self.inputs_fn, self.nb, self.gen_kw = model, inputs_fn, num_beams, gen_kw
+        self.side = torch.cuda.Stream()
+        self.stages = {}
+
+    def _encode(self, batch, after):
+        """enqueue caption `batch`'s encoder side on the side stream, not before event `after` (the previous caption's staged data
+        have been copied out).  Returns (stage or None, inputs, event)."""
+        with torch.cuda.stream(self.side):
+            if after is not None:
+                self.side.wait_event(after)
+            src, src_mask, feats, kw = self.inputs_fn(batch)
+            stage = None
+            if src.shape[0] == 1:
+                S = src.shape[1]
+                stage = self.stages.get(S)
+                if stage is None:
+                    stage = self.stages[S] = EncodeStage(self.model, S, self.nb)
+                stage.encode(self.model, src, src_mask, image_features=feats, add_ner_ffn=self.gen_kw.get("add_ner_ffn", True), **kw)
+            elif feats is not None:
+                feats = feats.clone()                       # a graphed image tower overwrites its output at the next call (which runs ahead)
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+        return stage, (src, src_mask, feats, kw), ev
+
+    def __call__(self, batches):
+        """yields (batch, generated ids) in order"""
+        main = torch.cuda.current_stream()
+        it = iter(batches)
+        try:
+            cur = next(it)
+        except StopIteration:
+            return
+        start = torch.cuda.Event()
+        start.record(main)                                  # inputs prepared on the caller's stream are complete
+        pend = self._encode(cur, start)
+        while cur is not None:
+            stage, (src, src_mask, feats, kw), ev = pend
+            main.wait_event(ev)
+            nxt = next(it, None)
+            if stage is not None:
+                # staged data -> the decoder's live buffers happens inside generate() (begin_staged) at the head of the main
+                # stream's work for this caption; the next caption's encoder side may overwrite the stage after that point
+                ses_ready = torch.cuda.Event()
+                gen = self.model.generate(input_ids=src, attention_mask=src_mask, num_beams=self.nb, encoded=stage,
+                                          _after_begin=(lambda: (ses_ready.record(main), self._prefetch(nxt, ses_ready))) if nxt is not None else None,
+                                          **self.gen_kw)
+            else:
+                if nxt is not None:
+                    done = torch.cuda.Event(); done.record(main)
+                    self._prefetch(nxt, done)
+                gen = self.model.generate(input_ids=src, attention_mask=src_mask, num_beams=self.nb, image_features=feats, **kw, **self.gen_kw)
+            yield cur, gen
+            cur, pend = nxt, (self._next if nxt is not None else None)
+
+    def _prefetch(self, batch, after):
+        self._next = self._encode(batch, after)
+
+
 @torch.no_grad()
 def generate(model, input_ids=None, attention_mask=None, num_beams=1, max_length=20, length_penalty=1.0, early_stopping=False,
              no_repeat_ngram_size=0, min_length=0, forced_eos_token_id="config", forced_bos_token_id=None, image_features=None,
              face_features=None, face_mask=None, name_ids=None, name_mask=None, add_ner_ffn=True, use_graphs=True, device_beams=True,
-             return_nbest=False, **unused):
+             return_nbest=False, encoded=None, _after_begin=None, **unused):
     """GenerationMixin.generate(do_sample=False) semantics of transformers 4.18 for this model (greedy = 1 beam).
     Returns int64 [B, L] starting with decoder_start_token_id, padded with pad_token_id.
     Keyword defaults are the LIBRARY defaults; the defaults a hub checkpoint's config.json adds on top (what the reference's
@@ -488,18 +608,16 @@ def generate(model, input_ids=None, attention_mask=None, num_beams=1, max_length
     B = input_ids.shape[0]
     nb = num_beams
     R = B * nb
-    mask_u8 = attention_mask.to(torch.uint8) if attention_mask.dtype != torch.uint8 else attention_mask
-    def run_encoder(ids, m8, img, nids, nmask, faces, fmask):
-        return model.model.encoder(input_ids=ids, attention_mask=m8, image_features=img, name_ids=nids, name_mask=nmask,
-                                   face_features=faces, face_mask=fmask, add_ner_ffn=add_ner_ffn)["last_hidden_state"]
-    if use_graphs:
-        ge = model.__dict__.setdefault("_graphed_encoders", {})
-        if add_ner_ffn not in ge:
-            ge[add_ner_ffn] = GraphedCall(run_encoder)
-        enc_h = ge[add_ner_ffn](input_ids, mask_u8, image_features, name_ids, name_mask, face_features, face_mask)
+    dev = model.emb16_pad.device
+    if encoded is not None:
+        # the encoder side of this caption ran ahead on another stream (EncodeStage / CaptionPipeline): K/V and mask are staged
+        if B != 1 or encoded.nb != nb:
+            raise ValueError("generate(encoded=...): staged encoding is for one caption and the same beam count")
+        enc_h, mask_u8, S, d = None, None, encoded.S, encoded.d
     else:
-        enc_h = run_encoder(input_ids, mask_u8, image_features, name_ids, name_mask, face_features, face_mask)
-    S, d = enc_h.shape[1], enc_h.shape[2]
+        mask_u8 = attention_mask.to(torch.uint8) if attention_mask.dtype != torch.uint8 else attention_mask
+        enc_h = _run_encoder(model, use_graphs, add_ner_ffn, input_ids, mask_u8, image_features, name_ids, name_mask, face_features, face_mask)
+        S, d = enc_h.shape[1], enc_h.shape[2]
     device_beams = bool(device_beams) and nb <= 16 and 2 * nb * nb <= 128 and max_length <= 512
     key = (R, S, max_length, nb, no_repeat_ngram_size, min_length, forced_eos_token_id, forced_bos_token_id,
            (float(length_penalty), bool(early_stopping)) if device_beams else None)
@@ -510,7 +628,12 @@ def generate(model, input_ids=None, attention_mask=None, num_beams=1, max_length
                                             forced_bos=forced_bos_token_id)
         if device_beams:
             ses.enable_device_beams(B, length_penalty, early_stopping, pad)
-    ses.dec.begin(enc_h, mask_u8, nb)
+    if encoded is not None:
+        ses.dec.begin_staged(encoded)
+    else:
+        ses.dec.begin(enc_h, mask_u8, nb)
+    if _after_begin is not None:
+        _after_begin()                                 # CaptionPipeline: the next caption's encoder side goes out before this beam search
     if device_beams:
         # on-device bookkeeping: the positions are enqueued back to back; ONE device->host copy of the final state
         try:
@@ -542,7 +665,7 @@ def generate(model, input_ids=None, attention_mask=None, num_beams=1, max_length
                 res[b, len(o)] = eos
         if was_training:
             model.train()
-        return (res.to(enc_h.device), nbest) if return_nbest else res.to(enc_h.device)
+        return (res.to(dev), nbest) if return_nbest else res.to(dev)
 
     seqs = [[start] for _ in range(R)]
     beam_scores = [0.0 if (r % nb) == 0 else -1e9 for r in range(R)]
@@ -550,7 +673,6 @@ def generate(model, input_ids=None, attention_mask=None, num_beams=1, max_length
     done = [False] * B
     cur_len = 1
     Kc = 2 * nb
-    dev = enc_h.device
     new_src = list(range(R))
     while True:
         t = cur_len - 1

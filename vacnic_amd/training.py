@@ -292,12 +292,17 @@ def train_step(model, guide, optimizer, batch, args: TrainArgs, ready=None, towe
     return out4
 
 
-def _model_inputs(net, batch):
-    """masks + frozen-tower features for one batch, as every reference loop builds them (TRAIN:267-276,408-421,491-504)."""
+def _model_inputs(net, batch, graphed=False):
+    """masks + frozen-tower features for one batch, as every reference loop builds them (TRAIN:267-276,408-421,491-504).
+    graphed: the image tower as a hipGraph per batch shape (caption generation at batch 1: ~250 launches of microseconds each)."""
     cfg = net.config
     src = batch["article_ids"]
     src_mask, _ = K.prep_ids(src, cfg.pad_token_id)
-    feats = extract_clip_img_feat(net.clip_model, batch["img_tensor"])[image_feature_index(cfg)]
+    if graphed:
+        from .models.clip_vit import graphed_clip_img_feat
+        feats = graphed_clip_img_feat(net.clip_model)(batch["img_tensor"])[image_feature_index(cfg)]
+    else:
+        feats = extract_clip_img_feat(net.clip_model, batch["img_tensor"])[image_feature_index(cfg)]
     kw = {}
     if not cfg.only_image:
         names_mask, _ = K.prep_ids(batch["names_art_ids"], cfg.pad_token_id)
@@ -334,18 +339,30 @@ def eval_epoch(model, batches, device="cuda"):
 
 
 @torch.no_grad()
-def gen_caption_from_loader_bart(model, batches, beam_size, max_length, device="cuda", length_penalty=1.0, plm_type=None, **gen_kw):
+def gen_caption_from_loader_bart(model, batches, beam_size, max_length, device="cuda", length_penalty=1.0, plm_type=None, pipeline=True,
+                                 **gen_kw):
     """TRAIN:480-530 (the generation half; BLEU/ROUGE/CIDEr/METEOR scoring and detokenisation are outside SURVEY §8):
     out_dict[step] = {"gt": target ids, "gen": generated ids} with `model.generate(num_beams=beam_size, max_length=max_length)`;
     `length_penalty` is the extra knob of the stand-alone generator (DDPINF:38,867).  Arguments the reference leaves to the model's
     config (no_repeat_ngram_size, early_stopping, forced BOS/EOS) default to the hub checkpoint's (config.HUB_GENERATION_DEFAULTS,
-    keyed by `plm_type`); `gen_kw` overrides them."""
+    keyed by `plm_type`); `gen_kw` overrides them.  pipeline: overlap the next caption's encoder side with this caption's beam search."""
     net = model.module if isinstance(model, DistributedDataParallel) else model
     was_training = net.training
     net.eval()
     out_dict = {}
     from .config import generation_defaults
     gkw = dict(generation_defaults(plm_type), **gen_kw)        # what `model.generate(num_beams, max_length)` inherits from the hub config
+    if pipeline and str(device).startswith("cuda"):
+        # two-stage pipeline over the captions (generate.CaptionPipeline): image tower + encoder + cross K/V of caption i + 1 on a side
+        # stream while caption i is decoded; same ids as the loop below
+        from .generate import CaptionPipeline
+        pipe = CaptionPipeline(net, lambda b: _model_inputs(net, b, graphed=True), beam_size, max_length=max_length,
+                               length_penalty=length_penalty, add_ner_ffn=True, **gkw)
+        with torch.no_grad():
+            for step, (batch, gen) in enumerate(pipe(to_device(b, device) for b in batches)):
+                out_dict[step] = {"gt": batch["caption_ids"].tolist(), "gen": gen.tolist()}
+        net.train(was_training)
+        return out_dict
     for step, batch in enumerate(batches):
         batch = to_device(batch, device)
         src, src_mask, feats, kw = _model_inputs(net, batch)
