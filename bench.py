@@ -267,10 +267,15 @@ def config5_id_check(model, cfg):
             cls = extract_clip_img_feat(model.clip_model, b["img_tensor"])[1]
             os.environ["VACNIC_DECODE_PER_OP"] = "1"
             model.__dict__.pop("_decode_sessions", None)
-            ids_per_op = _config5_generate(model, b, mask, nmask, cls, use_graphs=False).cpu()
+            ids_per_op, nb_per_op = _config5_generate(model, b, mask, nmask, cls, use_graphs=False, return_nbest=True)
+            ids_per_op = ids_per_op.cpu()
             os.environ["VACNIC_DECODE_PER_OP"] = "0"
             model.__dict__.pop("_decode_sessions", None)
-            ids_step = _config5_generate(model, b, mask, nmask, cls, use_graphs=False).cpu()
+            ids_step, nb_step = _config5_generate(model, b, mask, nmask, cls, use_graphs=False, return_nbest=True)
+            ids_step = ids_step.cpu()
+            # when the two captions differ: is the per-op chain's best hypothesis on the step kernel's n-best list, and how far behind?
+            other = next((k for k, (_, sq) in enumerate(nb_step[0]) if list(sq) == list(nb_per_op[0][0][1])), -1)
+            gap = float(nb_step[0][0][0] - nb_step[0][other][0]) if other >= 0 else None
             ses = list(model._decode_sessions.values())
             path = "decoder_step_slots" if ses and ses[0].dec.step_kernel and ses[0].dec.slots is not None else \
                    "decoder_step_barrier" if ses and ses[0].dec.step_kernel else "per_op"
@@ -302,6 +307,7 @@ def config5_id_check(model, cfg):
         out = {"ids_match_per_op": same, "first_differing_position": first, "default_path": path, "tokens": int(ids_step.shape[1]),
                "teacher_forced_max_logit_diff": round(worst, 4), "teacher_forced_clear_decisions": decided,
                "teacher_forced_clear_decisions_agree": agree,
+               "per_op_best_rank_in_step_nbest": other, "length_normalised_score_gap_to_it": None if gap is None else round(gap, 6),
                "note": "full-size model, benchmark weights; generation ids of step kernel vs per-op chain + both fed the same 49 x 5 tokens / reorders"}
     finally:
         os.environ.pop("VACNIC_DECODE_PER_OP", None)
