@@ -42,6 +42,15 @@ _COMM_MODE = os.environ.get("VACNIC_DDP_COMM", "native")
 _EV_BASE = 256            # named-event slots [256, 512) of the library belong to the reducer (one per bucket)
 
 
+def _share_a_gpu(pg):
+    """do two ranks of the group sit on one card (CPU-side rehearsals of the multi-rank path on a one-GPU box)?"""
+    import socket
+    me = (socket.gethostname(), int(torch.cuda.current_device()))
+    everyone = [None] * dist.get_world_size(pg)
+    dist.all_gather_object(everyone, me, group=pg)
+    return len(set(everyone)) != len(everyone)
+
+
 class NativeComm:
     """one RCCL communicator through the C-ABI.  Raises when the ranks of the group do not sit on distinct GPUs (several ranks
     rehearsing on one card: RCCL refuses that) or librccl cannot be resolved: the caller then keeps the torch.distributed path."""
@@ -179,6 +188,10 @@ class DistributedDataParallel(torch.nn.Module):
             except Exception as e:                              # (ranks sharing one card, no librccl): torch.distributed carries the data
                 import sys
                 print(f"[vacnic_amd.ddp] native RCCL path unavailable ({e}); using torch.distributed collectives", file=sys.stderr)
+                if dist.get_backend(self.pg) == "gloo" and not _share_a_gpu(self.pg):
+                    # the control-plane group must not carry 1.7 GB of gradients per step through host memory: RCCL via torch then
+                    # (the failure above is symmetric — no librccl symbol, no communicator — so every rank arrives here)
+                    self.pg = dist.new_group(backend="nccl")
         if self.active:
             # (i) ctor broadcast of all params from rank 0 (TRAIN:87); buffers on this path are constants
             if self.native is not None:
