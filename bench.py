@@ -342,8 +342,8 @@ def decode_leg(model, cfg, n=6):
                 times.append(time.perf_counter() - t0)
             tokens = int(out.shape[1])
         # the same captions as a STREAM (the reference's generation loop walks a test loader at batch 1, TRAIN:480-530):
-        # generate.CaptionPipeline enqueues caption i + 1's image tower, encoder and cross K/V on a side stream before caption i's
-        # beam search.  Whole-loop wall time / captions, ids compared with the sequential loop's.
+        # generate.CaptionPipeline enqueues caption i + 2's image tower and caption i + 1's encoder + cross K/V on side streams before
+        # caption i's beam search.  Whole-loop wall time / captions, ids compared with the sequential loop's.
         from vacnic_amd.generate import CaptionPipeline
         batches = [_config5_inputs(cfg, 42, i)[0] for i in range(n + 2)]
         seq_ids = []
@@ -369,8 +369,8 @@ def decode_leg(model, cfg, n=6):
            "value": round(1.0 / t_pipe, 2) if same else round(1.0 / t, 2),
            "unit": "captions/s", "ms_per_caption": round((t_pipe if same else t) * 1e3, 1), "tokens": tokens, "n": len(batches),
            "includes": "ViT + encoder + beam search",
-           "mode": ("stream of captions, two-stage pipeline: caption i+1's image tower / encoder / cross K/V on a side stream during caption i's "
-                    "beam search (generate.CaptionPipeline, the path of gen_caption_from_loader_bart)") if same else "one caption at a time",
+           "mode": ("stream of captions, pipelined: caption i+2's image tower and caption i+1's encoder / cross K/V on side streams during "
+                    "caption i's beam search (generate.CaptionPipeline, the path of gen_caption_from_loader_bart)") if same else "one caption at a time",
            "one_caption_at_a_time": {"value": round(1.0 / t, 2), "latency_ms_per_caption": round(t * 1e3, 1), "n": len(times)},
            "pipeline_ids_equal_sequential": same}
     res["id_check"] = check

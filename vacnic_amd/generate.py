@@ -519,69 +519,91 @@ class EncodeStage:
 
 class CaptionPipeline:
     """model.generate over a stream of single captions (test_batch_size 1, the reference's generation loop TRAIN:480-530) as a
-    two-stage pipeline: the image tower, the encoder and the cross-attention K/V projection of caption i + 1 are enqueued on a side
-    stream BEFORE the beam search of caption i is — they do not depend on it, and the beam search is a chain of latency-bound
-    launches that leaves most of the GPU idle.  Same ids as the sequential loop (the kernels are the same, only their streams
-    differ).  `inputs_fn(batch)` -> (input_ids, attention_mask, image_features, kw) builds the masks and runs the image tower
-    (training._model_inputs); it is called under the side stream.  Batches with more than one caption take the plain path."""
+    pipeline of three stages on three streams: while caption i is in its beam search (a chain of latency-bound launches that
+    leaves most of the GPU idle), the encoder and the cross-attention K/V projection of caption i + 1 run on a second stream and the
+    masks + image tower of caption i + 2 on a third — none of them depends on the beam search.  Same ids as the sequential loop
+    (the kernels are the same, only their streams differ).  `inputs_fn(batch)` -> (input_ids, attention_mask, image_features, kw)
+    builds the masks and runs the image tower (training._model_inputs).  Batches with more than one caption decode through the
+    plain generate() with their inputs_fn ahead."""
 
     def __init__(self, model, inputs_fn, num_beams, **gen_kw):
         self.model, self.inputs_fn, self.nb, self.gen_kw = model, inputs_fn, num_beams, gen_kw
-        self.side = torch.cuda.Stream()                     # (a higher or lower stream priority changes nothing: 34.7-34.8 ms per caption either way)
+        # (stream priorities change nothing: 34.7-34.8 ms per caption with one side stream either way)
+        self.s_img, self.s_enc = torch.cuda.Stream(), torch.cuda.Stream()
         self.stages = {}
 
-    def _encode(self, batch, after):
-        """enqueue caption `batch`'s encoder side on the side stream, not before event `after` (the previous caption's staged data
-        have been copied out).  Returns (stage or None, inputs, event)."""
-        with torch.cuda.stream(self.side):
-            if after is not None:
-                self.side.wait_event(after)
+    def _inputs(self, batch, after):
+        """stage A (image stream): masks + image tower of `batch`, not before event `after` (its tensors are on the device)"""
+        with torch.cuda.stream(self.s_img):
+            self.s_img.wait_event(after)
             src, src_mask, feats, kw = self.inputs_fn(batch)
-            stage = None
-            if src.shape[0] == 1:
-                S = src.shape[1]
-                stage = self.stages.get(S)
-                if stage is None:
-                    stage = self.stages[S] = EncodeStage(self.model, S, self.nb)
-                stage.encode(self.model, src, src_mask, image_features=feats, add_ner_ffn=self.gen_kw.get("add_ner_ffn", True), **kw)
-            elif feats is not None:
-                feats = feats.clone()                       # a graphed image tower overwrites its output at the next call (which runs ahead)
+            if feats is not None:
+                feats = feats.clone()                       # a graphed image tower overwrites its output at its next call (which runs ahead)
             ev = torch.cuda.Event()
-            ev.record(self.side)
-        return stage, (src, src_mask, feats, kw), ev
+            ev.record(self.s_img)
+        return {"batch": batch, "inputs": (src, src_mask, feats, kw), "a": ev, "stage": None, "b": ev}
+
+    def _encode(self, ent, after):
+        """stage B (encoder stream): encoder + cross K/V of one caption into the EncodeStage, not before `after` (the previous caption's
+        staged data have been copied into the decoder's buffers)"""
+        src, src_mask, feats, kw = ent["inputs"]
+        if src.shape[0] != 1:
+            return
+        with torch.cuda.stream(self.s_enc):
+            self.s_enc.wait_event(ent["a"])
+            if after is not None:
+                self.s_enc.wait_event(after)
+            S = src.shape[1]
+            stage = self.stages.get(S)
+            if stage is None:
+                stage = self.stages[S] = EncodeStage(self.model, S, self.nb)
+            stage.encode(self.model, src, src_mask, image_features=feats, add_ner_ffn=self.gen_kw.get("add_ner_ffn", True), **kw)
+            ev = torch.cuda.Event()
+            ev.record(self.s_enc)
+        ent["stage"], ent["b"] = stage, ev
 
     def __call__(self, batches):
         """yields (batch, generated ids) in order"""
         main = torch.cuda.current_stream()
         it = iter(batches)
-        try:
-            cur = next(it)
-        except StopIteration:
+
+        def fetch():
+            b = next(it, None)
+            if b is None:
+                return None
+            ready = torch.cuda.Event()
+            ready.record(main)                              # the caller's host-to-device copies of this batch were enqueued on `main`
+            return self._inputs(b, ready)
+
+        cur = fetch()
+        if cur is None:
             return
-        start = torch.cuda.Event()
-        start.record(main)                                  # inputs prepared on the caller's stream are complete
-        pend = self._encode(cur, start)
+        self._encode(cur, None)
+        nxt = fetch()
         while cur is not None:
-            stage, (src, src_mask, feats, kw), ev = pend
-            main.wait_event(ev)
-            nxt = next(it, None)
-            if stage is not None:
-                # staged data -> the decoder's live buffers happens inside generate() (begin_staged) at the head of the main
-                # stream's work for this caption; the next caption's encoder side may overwrite the stage after that point
-                ses_ready = torch.cuda.Event()
-                gen = self.model.generate(input_ids=src, attention_mask=src_mask, num_beams=self.nb, encoded=stage,
-                                          _after_begin=(lambda: (ses_ready.record(main), self._prefetch(nxt, ses_ready))) if nxt is not None else None,
+            main.wait_event(cur["b"])
+            src, src_mask, feats, kw = cur["inputs"]
+            ahead = {}
+
+            def advance(copied):
+                # the next caption's encoder side may overwrite the stage once this caption's copy out of it is enqueued (`copied`);
+                # the caption after that gets its image tower
+                if nxt is not None:
+                    self._encode(nxt, copied)
+                    ahead["e"] = fetch()
+
+            if cur["stage"] is not None:
+                def hook():
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    advance(ev)
+                gen = self.model.generate(input_ids=src, attention_mask=src_mask, num_beams=self.nb, encoded=cur["stage"], _after_begin=hook,
                                           **self.gen_kw)
             else:
-                if nxt is not None:
-                    done = torch.cuda.Event(); done.record(main)
-                    self._prefetch(nxt, done)
+                advance(None)
                 gen = self.model.generate(input_ids=src, attention_mask=src_mask, num_beams=self.nb, image_features=feats, **kw, **self.gen_kw)
-            yield cur, gen
-            cur, pend = nxt, (self._next if nxt is not None else None)
-
-    def _prefetch(self, batch, after):
-        self._next = self._encode(batch, after)
+            yield cur["batch"], gen
+            cur, nxt = nxt, ahead.get("e")
 
 
 @torch.no_grad()
