@@ -337,11 +337,30 @@ extern "C" int vacnic_image_u8_normalize(const uint8_t* src, const uint8_t* flip
   return VACNIC_OK;
 }
 
-// zero-fill on the caller's stream (a memset node: graph-capturable, no kernel) — the fp32 accumulators of split-K GEMMs
+namespace {
+__global__ __launch_bounds__(256) void zero_words_kernel(unsigned* __restrict__ p, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = 0u;
+}
+}  // namespace
+
+// zero-fill on the caller's stream — the fp32 accumulators of split-K GEMMs, the arrival counters of the split-K fix-up.  A memset
+// (no kernel) on an ordinary stream; while the stream is being CAPTURED into a hipGraph a fill kernel instead (VACNIC_ZERO_MEMSET_IN_GRAPHS=1
+// keeps the memset node): see DESIGN section 0, item 5 (c).
 extern "C" int vacnic_zero_bytes(void* ptr, int64_t bytes, void* stream) {
   VPLAN_REC(vacnic_zero_bytes, ptr, bytes, stream);
   VCHECK(ptr && bytes >= 0, VACNIC_BAD_SHAPE, "zero_bytes: bad operand");
   if (bytes == 0) return VACNIC_OK;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  static const bool memset_in_graphs = getenv("VACNIC_ZERO_MEMSET_IN_GRAPHS") && atoi(getenv("VACNIC_ZERO_MEMSET_IN_GRAPHS"));
+  if (!memset_in_graphs && (((uintptr_t)ptr | (uintptr_t)bytes) & 3) == 0 && hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess &&
+      cs == hipStreamCaptureStatusActive) {
+    const long n = (long)(bytes >> 2);
+    long nb = (n + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (unsigned*)ptr, n);
+    VLAUNCH_CHECK();
+    return VACNIC_OK;
+  }
   if (hipMemsetAsync(ptr, 0, (size_t)bytes, (hipStream_t)stream) != hipSuccess) {
     vacnic_set_error("zero_bytes: hipMemsetAsync failed");
     return VACNIC_HIP_ERROR;

@@ -150,6 +150,7 @@ def _load_tuned():
 _load_tuned()
 
 
+_SMALLM_SPLIT = __import__("os").environ.get("VACNIC_SMALLM_SPLIT", "1") != "0"      # A/B: 0 = no K slices for small-M inference GEMMs
 _TUNED_FIXUP = __import__("os").environ.get("VACNIC_GEMM_FIXUP_TUNED", "1") != "0"      # A/B: 0 = ignore the fix-up entries of gemm_tuned.json
 _FIX = {}                 # launch stream -> [workspace (uint8), counters (int32, all zero between launches)]
 _FIX_CAPTURE = {}         # the same for launches recorded by a hipGraph capture on that stream (buffers from the graph's private pool)
@@ -205,6 +206,12 @@ def gemm(x, w, M, N, K, *, bias=None, out=None, ldx=None, ldw=None, ldo=None, x_
             tile_hint = t[0] or -1
             if out_mode == 2:
                 split_k = t[1] if _SPLIT_SCALE == 1.0 else max(1, min(32, int(t[1] * _SPLIT_SCALE)))
+        elif (t is None and _SMALLM_SPLIT and split_k == 1 and not fixup and 8 < M <= 1024 and K >= 4096 and N <= 2048 and out_mode != 2
+              and xsum is None and not x_kstrided and not w_kstrided and not torch.is_grad_enabled()):
+            # one caption's encoder / ViT pass (batch 1: M = 512 tokens, 257 patches), fc2: 64 x 128 tiles give <= 64 workgroups, each
+            # alone on its CU with a 64-iteration K loop bound by the latency of its own loads (30 us); four K slices through the
+            # ordered fix-up: 17-18 us (profiles/r4_small_m_gemm.txt).  K = 1024 launches sit on an 11 us floor either way.
+            tile_hint, split_k, fixup = 64, 4, True
     if tile_hint < 0:
         tile_hint = 0
     st = _stream()
