@@ -37,7 +37,7 @@ for name, extra in F5.CASES:
         d = (encs[-1] - encs[0]).abs()
         torch.cuda.synchronize()
         for st_, (ws_, cnt_) in K._FIX_CAPTURE.items():
-            print(f"    capture-table stream {st_:#x}: ws {ws_.data_ptr():#x} +{ws_.numel()}  counters {cnt_.data_ptr():#x} +{cnt_.numel() * 4}  non-zero counters {int((cnt_ != 0).sum())}")
+            print(f"    capture-table {st_}: ws {ws_.data_ptr():#x} +{ws_.numel()}  counters {cnt_.data_ptr():#x} +{cnt_.numel() * 4}  non-zero counters {int((cnt_ != 0).sum())}")
         for st_, (ws_, cnt_) in K._FIX.items():
             print(f"    eager-table   stream {st_:#x}: ws {ws_.data_ptr():#x} +{ws_.numel()}  counters {cnt_.data_ptr():#x} +{cnt_.numel() * 4}  non-zero counters {int((cnt_ != 0).sum())}")
         a, b = out[0].tolist(), want[0].tolist()

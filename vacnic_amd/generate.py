@@ -52,6 +52,7 @@ class GraphedCall:
             static = [a.clone() if a is not None else None for a in args]
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
+            K.new_capture_scope()                          # this graph may replay beside other graphs (CaptionPipeline): private fix-up buffers
             try:
                 with torch.cuda.graph(g):
                     out = self.fn(*static)

@@ -150,25 +150,37 @@ def _load_tuned():
 _load_tuned()
 
 
-_SMALLM_SPLIT = __import__("os").environ.get("VACNIC_SMALLM_SPLIT", "1") != "0"      # A/B: 0 = no K slices for small-M inference GEMMs
+_SMALLM_SPLIT = __import__("os").environ.get("VACNIC_SMALLM_SPLIT", "0") != "0"      # 1: K slices for the batch-1 fc2 GEMMs of the encoder / ViT (off: see DESIGN section 0, item 5 (c))
 _TUNED_FIXUP = __import__("os").environ.get("VACNIC_GEMM_FIXUP_TUNED", "1") != "0"      # A/B: 0 = ignore the fix-up entries of gemm_tuned.json
 _FIX = {}                 # launch stream -> [workspace (uint8), counters (int32, all zero between launches)]
 _FIX_CAPTURE = {}         # the same for launches recorded by a hipGraph capture on that stream (buffers from the graph's private pool)
 _FIX_CAPTURE_FLOOR = 0    # bytes (a debugging aid: tools/enc_graph_check.py)
+_CAPTURE_SCOPE = 0        # bumped by whoever captures a graph that may replay beside other graphs (new_capture_scope)
 _FIX_OLD = []             # outgrown workspaces: kernels already enqueued may still use them
+
+
+def new_capture_scope():
+    """fix-up buffers of launches captured from now on are private to the graph being captured: torch captures every graph on ONE
+    capture stream, so the per-stream table alone would hand the image-tower graph and the encoder graph the same counters — fine while
+    graphs replay one after the other on one stream, wrong once generate.CaptionPipeline replays them on two streams at once."""
+    global _CAPTURE_SCOPE
+    _CAPTURE_SCOPE += 1
 
 
 def _fix_buffers(stream, M, N, split_k):
     """split-K fix-up buffers of the launch stream: launches on ONE stream run in order, so they share a workspace that only
     grows (persistent: the same addresses at every replay of a launch plan), and the arrival counters, which every launch leaves
-    zeroed.  Kept out of torch's per-step allocations on purpose.  The counters of a new buffer are cleared by a memset node ON THE
-    LAUNCH STREAM (ordered before the GEMM whatever stream torch considers current; legal inside a stream capture).  Launches
-    recorded by a hipGraph capture get buffers of their own (allocated from the graph's pool): a captured launch and an eager
-    one must never share counters, and graphs captured on one stream replay in order."""
+    zeroed.  Kept out of torch's per-step allocations on purpose.  The counters of a new buffer are cleared ON THE LAUNCH STREAM
+    (vacnic_zero_bytes: ordered before the GEMM whatever stream torch considers current; a fill kernel inside a stream capture).
+    Launches recorded by a hipGraph capture get buffers of their own (allocated from the graph's pool): a captured launch and an
+    eager one must never share counters; graphs captured in one scope (new_capture_scope) replay in order on one stream."""
     need = int(_lib.lib.vacnic_gemm_workspace_bytes(M, N, split_k))
     ncnt = int(_lib.lib.vacnic_gemm_counters(M, N))
-    table = _FIX_CAPTURE if torch.cuda.is_current_stream_capturing() else _FIX
-    ent = table.get(stream)
+    capturing = torch.cuda.is_current_stream_capturing()
+    table = _FIX_CAPTURE if capturing else _FIX
+    # graphs that may replay CONCURRENTLY (generate.GraphedCall: image tower / encoder) never share buffers
+    key = (stream, _CAPTURE_SCOPE) if capturing else stream
+    ent = table.get(key)
     if ent is None or ent[0].numel() < need or ent[1].numel() < ncnt:
         floor = _FIX_CAPTURE_FLOOR if table is _FIX_CAPTURE else 64 << 20
         ws = torch.empty(max(need, ent[0].numel() if ent else 0, floor), device="cuda", dtype=torch.uint8)
@@ -176,7 +188,7 @@ def _fix_buffers(stream, M, N, split_k):
         call("vacnic_zero_bytes", cnt.data_ptr(), cnt.numel() * 4, stream)
         if ent is not None:
             _FIX_OLD.append(ent)
-        ent = table[stream] = [ws, cnt]
+        ent = table[key] = [ws, cnt]
     return ent
 
 
