@@ -491,7 +491,9 @@ int vacnic_lmhead_ce_rowp(const float* row_lse, const int64_t* targets, const fl
 int vacnic_lmhead_ce_dlogits(const vacnic_lmhead_ce_args* a, int64_t col0, int64_t ncols, void* dl, int64_t lddl,
                              const float* rowp, void* stream);
 
-/* zero `bytes` bytes at `ptr` on `stream` (memset node; used for the fp32 accumulators of split-K GEMMs instead of a fill kernel) */
+/* zero `bytes` bytes at `ptr` on `stream`: the fp32 accumulators of split-K GEMMs, the arrival counters of the split-K fix-up.
+ * hipMemsetAsync on an ordinary stream; a fill kernel while `stream` is being captured into a hipGraph (a memset NODE is not
+ * reliably ordered before the kernel node that follows it when the graph replays). */
 int vacnic_zero_bytes(void* ptr, int64_t bytes, void* stream);
 
 /* ---- launch plans: a step's C-ABI call sequence recorded once and replayed from C++ -----------------------------------------
