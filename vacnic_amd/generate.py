@@ -52,9 +52,9 @@ class GraphedCall:
             static = [a.clone() if a is not None else None for a in args]
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
-            K.new_capture_scope()                          # this graph may replay beside other graphs (CaptionPipeline): private fix-up buffers
             try:
-                with torch.cuda.graph(g):
+                # (this graph may replay beside other graphs — CaptionPipeline — so its split-K fix-up buffers are its own)
+                with K.capture_scope(("graphed-call", id(g))), torch.cuda.graph(g):
                     out = self.fn(*static)
             except _lib.VacnicError:
                 raise                                     # a kernel / argument error is a bug, not a capture limitation
@@ -393,7 +393,7 @@ class DecodeSession:
                 if g is None:
                     g = torch.cuda.CUDAGraph()
                     torch.cuda.synchronize()
-                    with torch.cuda.graph(g, pool=self.pool):
+                    with K.capture_scope(("decode-session", id(self))), torch.cuda.graph(g, pool=self.pool):
                         self.body(t)
                     if self.pool is None:
                         self.pool = g.pool()
@@ -462,7 +462,7 @@ class DecodeSession:
             if g is None:
                 g = torch.cuda.CUDAGraph()
                 torch.cuda.synchronize()
-                with torch.cuda.graph(g, pool=self.pool):
+                with K.capture_scope(("decode-session", id(self))), torch.cuda.graph(g, pool=self.pool):
                     self.outs[t] = self.body(t)
                 if self.pool is None:
                     self.pool = g.pool()

@@ -4,6 +4,8 @@ PyTorch here is plumbing only (device memory + the current HIP stream); every ar
 path is a hand-written gfx950 kernel in libvacnic_hip.so.  All wrappers launch on
 `torch.cuda.current_stream()` so they are hipGraph-capturable, and all fail loudly on CPU tensors.
 """
+import contextlib
+
 import torch
 
 from . import _lib
@@ -155,16 +157,22 @@ _TUNED_FIXUP = __import__("os").environ.get("VACNIC_GEMM_FIXUP_TUNED", "1") != "
 _FIX = {}                 # launch stream -> [workspace (uint8), counters (int32, all zero between launches)]
 _FIX_CAPTURE = {}         # the same for launches recorded by a hipGraph capture on that stream (buffers from the graph's private pool)
 _FIX_CAPTURE_FLOOR = 0    # bytes (a debugging aid: tools/enc_graph_check.py)
-_CAPTURE_SCOPE = 0        # bumped by whoever captures a graph that may replay beside other graphs (new_capture_scope)
+_CAPTURE_SCOPE = 0        # owner of the graph being captured (capture_scope); 0: graphs that replay in order on one stream
 _FIX_OLD = []             # outgrown workspaces: kernels already enqueued may still use them
 
 
-def new_capture_scope():
-    """fix-up buffers of launches captured from now on are private to the graph being captured: torch captures every graph on ONE
-    capture stream, so the per-stream table alone would hand the image-tower graph and the encoder graph the same counters — fine while
-    graphs replay one after the other on one stream, wrong once generate.CaptionPipeline replays them on two streams at once."""
+@contextlib.contextmanager
+def capture_scope(tag):
+    """fix-up buffers of launches captured inside this block are private to `tag` (any hashable: the object that owns the graphs).
+    torch captures every graph on ONE capture stream, so the per-stream table alone would hand the image-tower graph, the encoder
+    graph and a decode session's graphs the same workspace and counters — fine while graphs replay one after the other on one stream,
+    wrong once generate.CaptionPipeline replays them on several streams at once."""
     global _CAPTURE_SCOPE
-    _CAPTURE_SCOPE += 1
+    prev, _CAPTURE_SCOPE = _CAPTURE_SCOPE, tag
+    try:
+        yield
+    finally:
+        _CAPTURE_SCOPE = prev
 
 
 def _fix_buffers(stream, M, N, split_k):
@@ -173,7 +181,7 @@ def _fix_buffers(stream, M, N, split_k):
     zeroed.  Kept out of torch's per-step allocations on purpose.  The counters of a new buffer are cleared ON THE LAUNCH STREAM
     (vacnic_zero_bytes: ordered before the GEMM whatever stream torch considers current; a fill kernel inside a stream capture).
     Launches recorded by a hipGraph capture get buffers of their own (allocated from the graph's pool): a captured launch and an
-    eager one must never share counters; graphs captured in one scope (new_capture_scope) replay in order on one stream."""
+    eager one must never share counters; graphs captured in one scope (capture_scope) replay in order on one stream."""
     need = int(_lib.lib.vacnic_gemm_workspace_bytes(M, N, split_k))
     ncnt = int(_lib.lib.vacnic_gemm_counters(M, N))
     capturing = torch.cuda.is_current_stream_capturing()
